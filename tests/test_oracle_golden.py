@@ -1,0 +1,174 @@
+"""Pins the CPU oracle (oracle/) against golden vectors produced by the reference itself
+(tools/gen_golden.py).  CPU only.  Tolerance: north_star's 1e-4 relative fp32, asserted
+norm-wise plus a max-abs bound (conftest.assert_close)."""
+import numpy as np
+import pytest
+
+from conftest import assert_close, load_golden, relerr
+
+
+def test_geometry(oracle_lib):
+    g = load_golden("geometry")
+    B, _, h, w = g["depth"].shape
+    cam, pix = oracle_lib.backproject_project(g["depth"], g["invK"], g["K"], g["T"], h, w)
+    assert_close(cam, g["cam_points"], what="cam_points")
+    # pix in [-1,1]: compare in pixel units so the tolerance means something
+    assert_close(pix, g["pix_coords"], rtol=1e-5, what="pix_coords")
+    eye = np.repeat(np.eye(4, dtype=np.float32)[None], B, 0)
+    _, pix_id = oracle_lib.backproject_project(g["depth"], g["invK"], g["K"], eye, h, w)
+    assert_close(pix_id, g["pix_coords_identity"], rtol=1e-5, what="KAT6 identity grid")
+    assert_close(oracle_lib.transformation_from_parameters(g["axisangle"], g["translation"]), g["T"], rtol=1e-6)
+    assert_close(oracle_lib.transformation_from_parameters(g["axisangle"], g["translation"], invert=True),
+                 g["T_invert"], rtol=1e-6)
+    s, d = oracle_lib.disp_to_depth(g["disp"], 0.1, 100.0)
+    assert_close(s, g["scaled_disp"], rtol=1e-6)
+    assert_close(d, g["depth_from_disp"], rtol=1e-6)
+
+
+@pytest.mark.parametrize("ty", ["inverse", "linear", "log"])
+def test_schedule(oracle_lib, ty):
+    g = load_golden("schedule")
+    D, f = int(g["ndepth"]), float(g["scale_fac"])
+    assert_close(oracle_lib.schedule_depth_range(g["prior"], D, f, None, ty), g["v2_" + ty], rtol=1e-6)
+    assert_close(oracle_lib.schedule_depth_range(g["prior"], D, f, g["z_trans"], ty), g["zv2_" + ty], rtol=1e-6)
+
+
+def test_schedule_unguarded(oracle_lib):
+    """1 + f*z <= 0 gives negative / non-finite hypotheses; reproduced, not fixed."""
+    g = load_golden("schedule")
+    out = oracle_lib.schedule_depth_range(g["prior"], int(g["ndepth"]), float(g["scale_fac"]), g["z_trans_bad"])
+    ref = g["zv2_inverse_bad"]
+    assert np.array_equal(np.isnan(out), np.isnan(ref))
+    fin = np.isfinite(ref)
+    assert np.array_equal(np.isfinite(out), fin)
+    assert_close(out[fin], ref[fin], rtol=1e-4)
+
+
+COSTVOL_CASES = ["small", "white", "oob", "zv2", "c64g8"]
+
+
+@pytest.mark.parametrize("tag", COSTVOL_CASES)
+def test_costvol_grouped(oracle_lib, tag):
+    g = load_golden("costvol_" + tag)
+    G = int(g["G"])
+    out = oracle_lib.costvol_grouped(g["ref"], g["src0"], g["K"], g["invK"], g["hyp"], g["pose"][:, 0], G)
+    assert_close(out, g["grouped0"], what="grouped volume " + tag)
+    cor, w = oracle_lib.fuse([out])
+    assert_close(cor, g["cor_feats"], what="cor_feats " + tag)
+    assert_close(w[0], g["cor_weight0"], rtol=1e-5, what="cor_weight " + tag)
+
+
+def test_costvol_full(oracle_lib):
+    g = load_golden("costvol_small")
+    out = oracle_lib.costvol(g["ref"], g["src0"], g["K"], g["invK"], g["hyp"], g["pose"][:, 0])
+    assert_close(out, g["cost_vol_full0"], what="(B,D,C,h,w) volume")
+    # KAT3: group g = mean(channel g, channel g+16)
+    B, D, C, h, w = out.shape
+    assert_close(out.reshape(B, D, 2, 16, h, w).mean(2), g["grouped0"], rtol=1e-6)
+
+
+@pytest.mark.parametrize("tag", COSTVOL_CASES)
+def test_costvol_backward(oracle_lib, tag):
+    g = load_golden("costvol_" + tag)
+    G = int(g["G"])
+    vol = oracle_lib.costvol_grouped(g["ref"], g["src0"], g["K"], g["invK"], g["hyp"], g["pose"][:, 0], G)
+    (gvol,) = oracle_lib.fuse_bwd(g["grad_out"], [vol])
+    d_ref, d_src = oracle_lib.costvol_grouped_bwd(gvol, g["ref"], g["src0"], g["K"], g["invK"], g["hyp"],
+                                                  g["pose"][:, 0])
+    assert_close(d_ref, g["d_ref"], what="d_ref " + tag)
+    assert_close(d_src, g["d_src0"], what="d_src " + tag)
+
+
+def test_costvol_twoframe_fusion(oracle_lib):
+    g = load_golden("costvol_twoframe")
+    G = int(g["G"])
+    vols = [oracle_lib.costvol_grouped(g["ref"], g["src%d" % f], g["K"], g["invK"], g["hyp"], g["pose"][:, f], G)
+            for f in range(2)]
+    cor, w = oracle_lib.fuse(vols)
+    assert_close(cor, g["cor_feats"], what="two-frame cor_feats")
+    for f in range(2):
+        assert_close(w[f], g["cor_weight%d" % f], rtol=1e-5)
+    gvols = oracle_lib.fuse_bwd(g["grad_out"], vols)
+    d_ref = 0
+    for f in range(2):
+        dr, ds = oracle_lib.costvol_grouped_bwd(gvols[f], g["ref"], g["src%d" % f], g["K"], g["invK"], g["hyp"],
+                                                g["pose"][:, f])
+        d_ref = d_ref + dr
+        assert_close(ds, g["d_src%d" % f], what="two-frame d_src%d" % f)
+    assert_close(d_ref, g["d_ref"], what="two-frame d_ref")
+
+
+def test_costvol_kat_identity_and_shift(oracle_lib):
+    """SURVEY section 4 KAT1 / KAT2."""
+    rng = np.random.default_rng(0)
+    B, C, h, w, D = 1, 32, 8, 16, 4
+    ref = rng.standard_normal((B, C, h, w)).astype(np.float32)
+    src = rng.standard_normal((B, C, h, w)).astype(np.float32)
+    K = np.array([[0.58 * w, 0, 0.5 * w, 0], [0, 1.92 * h, 0.5 * h, 0], [0, 0, 1, 0], [0, 0, 0, 1]], np.float32)[None]
+    invK = np.linalg.pinv(K[0]).astype(np.float32)[None]
+    hyp = np.full((B, D, h, w), 5.0, np.float32)
+    T = np.eye(4, dtype=np.float32)[None]
+    out = oracle_lib.costvol(ref, src, K, invK, hyp, T)
+    assert np.max(np.abs(out - (ref * src)[:, None])) < 2e-4  # KAT1 (coordinate round trip is not bit exact)
+    # KAT2: pure x translation at constant depth z shifts by fx*tx/z pixels, zero padded
+    z, shift = 5.0, 2
+    T2 = T.copy()
+    T2[0, 0, 3] = shift * z / (0.58 * w)
+    out2 = oracle_lib.costvol(ref, src, K, invK, hyp, T2)
+    exp = np.zeros_like(src)
+    exp[..., : w - shift] = src[..., shift:]
+    assert np.max(np.abs(out2 - (ref * exp)[:, None])) < 2e-4
+
+
+@pytest.mark.parametrize("tag", ["small", "border"])
+def test_warp(oracle_lib, tag):
+    g = load_golden("warp_" + tag)
+    out, pix = oracle_lib.warp(g["img"], g["depth"], g["K"], g["invK"], g["T"])
+    assert_close(pix, g["pix_coords"], rtol=1e-5, what="pix")
+    assert_close(out, g["warped"], what="warped")
+    mask = ((pix < -1) | (pix > 1)).sum(-1) > 0
+    assert (mask != g["mvs_mask"]).mean() < 2e-3  # boolean on a rounding knife edge
+    d_depth, d_T = oracle_lib.warp_bwd(g["grad_out"], g["img"], g["depth"], g["K"], g["invK"], g["T"])
+    assert_close(d_depth.reshape(g["d_depth"].shape), g["d_depth"], rtol=2e-4, atol_scale=5e-3, what="d_depth")
+    assert_close(d_T, g["d_T"], rtol=2e-4, what="d_T")
+
+
+def test_ssim_and_reprojection_loss(oracle_lib):
+    g = load_golden("ssim")
+    assert_close(oracle_lib.ssim(g["pred"], g["target"]), g["ssim"], what="ssim map")
+    assert_close(oracle_lib.reproj_loss(g["pred"], g["target"]), g["reproj"], what="reprojection loss")
+    assert_close(oracle_lib.reproj_loss(g["pred"], g["target"], ssim_w=0.0), g["reproj_l1only"], rtol=1e-6)
+    assert_close(oracle_lib.reproj_loss_bwd(g["grad_out"], g["pred"], g["target"]), g["d_pred"], rtol=2e-4,
+                 what="d_pred")
+    assert_close(oracle_lib.reproj_loss_bwd(g["grad_out"], g["pred"], g["target"], ssim_w=0.0), g["d_pred_l1only"],
+                 rtol=1e-6)
+    # KAT5
+    assert np.max(np.abs(oracle_lib.ssim(g["kat_x"], g["kat_x"]))) < 1e-6
+    assert_close(oracle_lib.ssim(np.zeros((1, 3, 8, 8)), np.ones((1, 3, 8, 8))), g["kat_const"], rtol=1e-6)
+    assert abs(float(g["kat_const"].ravel()[0]) - 0.49995) < 1e-5
+
+
+def test_smooth(oracle_lib):
+    g = load_golden("smooth")
+    assert abs(oracle_lib.smooth_loss(g["disp"], g["img"], True) - float(g["smooth_norm"])) < 1e-5 * float(g["smooth_norm"])
+    assert abs(oracle_lib.smooth_loss(g["disp"], g["img"], False) - float(g["smooth_raw"])) < 1e-5 * float(g["smooth_raw"])
+    assert_close(oracle_lib.smooth_loss_bwd(1.0, g["disp"], g["img"], True), g["d_disp"], what="smooth d_disp")
+
+
+def test_postvol(oracle_lib):
+    g = load_golden("postvol")
+    prob = oracle_lib.softmax_d(g["logits"])
+    hyp = g["hyp"]
+    assert_close(oracle_lib.entropy(prob), g["entropy"], rtol=1e-5)
+    assert_close(oracle_lib.localmax(prob, 1, 1 / hyp[:, -1], 1 / hyp[:, 0]), g["depth_r1"], rtol=1e-5)
+    assert_close(oracle_lib.localmax(prob, 2, 1 / hyp[:, -1], 1 / hyp[:, 0]), g["depth_r2"], rtol=1e-5)
+    # KAT4: one-hot at index d decodes to hypothesis D-1-d
+    D = hyp.shape[1]
+    onehot = np.zeros((1, D, 1, D), np.float32)
+    for d in range(D):
+        onehot[0, d, 0, d] = 1
+    kh = g["kat_hyp"]
+    out = oracle_lib.localmax(onehot, 1, 1 / kh[:, -1], 1 / kh[:, 0])
+    assert_close(out, g["kat_onehot_depth"], rtol=1e-5)
+    assert_close(out[0, 0], kh[0, ::-1, 0, 0], rtol=1e-4)
+    assert_close(oracle_lib.convex_upsample(g["up_depth"], g["up_mask"], 2), g["up_out"], rtol=1e-5)

@@ -1,0 +1,399 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ from the reference itself.
+
+Runs ONLY in the build container (needs /root/reference, imported read-only via
+tools/refload.py).  Every fixture is data: seeded synthetic inputs plus the
+outputs / gradients the reference's own PyTorch-CPU code (torch 2.10 CPU, fp32)
+produces for them.  No reference source text is stored.
+
+    python tools/gen_golden.py            # rewrites tests/golden/*.npz
+
+Reference functions driven (file:line in /root/reference/movedepth):
+  layers.py   BackprojectDepth 556-586, Project3D 589-621, generate_costvol 778-794,
+              schedule_depth_rangev2 256-284, schedule_depth_range_zv2 370-398,
+              SSIM 646-677, get_smooth_loss 630-643, localmax 796-812, entropy 862-863,
+              convex_upsample 200-214, disp_to_depth 400-409,
+              transformation_from_parameters 412-429
+  trainer.py  generate_images_pred 491-532, compute_reprojection_loss 535-550,
+              compute_losses 614-724, compute_fuse_losses 569-612;
+              the group-mean / confidence-fusion lines 358-363 are inline code in
+              process_batch, so they are driven by executing the same torch ops on
+              the reference's generate_costvol output (marked "inline" below).
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+from refload import load_reference  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+
+
+# ----------------------------------------------------------------------------- helpers
+def kitti_K(h, w, B):
+    """Normalised KITTI intrinsics scaled to (h, w); inv_K = pinv(K) (dataset contract a0)."""
+    K = np.array([[0.58, 0, 0.5, 0], [0, 1.92, 0.5, 0], [0, 0, 1, 0], [0, 0, 0, 1]], dtype=np.float32)
+    K[0, :] *= w
+    K[1, :] *= h
+    invK = np.linalg.pinv(K)
+    K = torch.from_numpy(np.repeat(K[None], B, 0).copy())
+    invK = torch.from_numpy(np.repeat(invK[None], B, 0).astype(np.float32).copy())
+    return K, invK
+
+
+def smooth_noise(shape, g, coarse=4, lo=0.0, hi=1.0):
+    """Low-pass noise: coarse uniform noise, bicubic-free bilinear upsample (well-conditioned taps)."""
+    *lead, H, W = shape
+    n = int(np.prod(lead))
+    c = torch.rand(n, 1, max(2, H // coarse), max(2, W // coarse), generator=g)
+    x = F.interpolate(c, size=(H, W), mode="bilinear", align_corners=True)
+    return (lo + (hi - lo) * x).reshape(*shape).contiguous()
+
+
+def npify(d):
+    out = {}
+    for k, v in d.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    return out
+
+
+def save(name, d):
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **npify(d))
+    print("%-28s %8.1f KB  (%d arrays)" % (name + ".npz", os.path.getsize(path) / 1024, len(d)))
+
+
+def poses(L, B, g, rot=0.01, trans=0.05, tz=None, invert=False):
+    aa = torch.randn(B, 1, 3, generator=g) * rot
+    t = torch.randn(B, 1, 3, generator=g) * trans
+    if tz is not None:
+        t[:, 0, 2] = torch.as_tensor(tz, dtype=torch.float32)
+    T = L.transformation_from_parameters(aa, t, invert=invert)
+    return aa, t, T
+
+
+# ----------------------------------------------------------------------------- fixtures
+def gen_geometry(L):
+    g = torch.Generator().manual_seed(101)
+    B, h, w = 2, 6, 10
+    K, invK = kitti_K(h, w, B)
+    depth = 2 + 20 * torch.rand(B, 1, h, w, generator=g)
+    aa, t, T = poses(L, B, g, rot=0.05, trans=0.3)
+    _, _, Tinv = aa, t, L.transformation_from_parameters(aa, t, invert=True)
+    bp, pj = L.BackprojectDepth(B, h, w), L.Project3D(B, h, w)
+    pts = bp(depth, invK)
+    pix = pj(pts, K, T)
+    # KAT6: identity pose returns the align_corners grid (up to fp32 rounding)
+    pix_id = pj(bp(depth, invK), K, torch.eye(4)[None].repeat(B, 1, 1))
+    disp = torch.rand(B, 1, h, w, generator=g)
+    sdisp, d2 = L.disp_to_depth(disp, 0.1, 100.0)
+    save("geometry", dict(K=K, invK=invK, depth=depth, axisangle=aa, translation=t, T=T, T_invert=Tinv,
+                          cam_points=pts, pix_coords=pix, pix_coords_identity=pix_id,
+                          disp=disp, scaled_disp=sdisp, depth_from_disp=d2))
+
+
+def gen_schedule(L):
+    g = torch.Generator().manual_seed(102)
+    B, h, w, D = 2, 5, 7, 8
+    prior = 2 + 20 * torch.rand(B, 1, h, w, generator=g)
+    out = dict(prior=prior, ndepth=D, scale_fac=0.3)
+    z = torch.tensor([0.9, -1.2]).reshape(B, 1, 1, 1)  # z_scale * T[2,3]; second flips the ordering
+    out["z_trans"] = z
+    for ty in ("inverse", "linear", "log"):
+        out["v2_" + ty] = L.schedule_depth_rangev2(prior, D, 0.3, type=ty)
+        out["zv2_" + ty] = L.schedule_depth_range_zv2(prior, D, 0.3, z, type=ty)
+    # no guard on 1 + f*z <= 0: negative / inf hypotheses are reproduced
+    zbad = torch.tensor([-3.5, -10.0 / 3.0]).reshape(B, 1, 1, 1)
+    out["z_trans_bad"] = zbad
+    with np.errstate(all="ignore"):
+        out["zv2_inverse_bad"] = L.schedule_depth_range_zv2(prior, D, 0.3, zbad, type="inverse")
+    save("schedule", out)
+
+
+def _fuse_inline(cvs, G):
+    """trainer.py:349-363 executed on reference generate_costvol outputs ("inline")."""
+    cor_weight_sum = 1e-8
+    cor_feats = 0
+    ws = []
+    for cv in cvs:
+        B, D, C, H, W = cv.shape
+        cg = cv.reshape(B, D, -1, G, H, W).mean(2)
+        wgt = torch.softmax(cg.mean(1), dim=1).max(1)[0]
+        ws.append(wgt)
+        cor_weight_sum = cor_weight_sum + wgt
+        cor_feats = cor_feats + wgt.unsqueeze(1).unsqueeze(1) * cg
+    cor_feats = cor_feats / cor_weight_sum.unsqueeze(1).unsqueeze(1)
+    return cor_feats, ws
+
+
+def gen_costvol(L):
+    def case(tag, seed, B, C, G, h, w, D, rot, trans, tz, nframes=1, white=False, sched="v2", ztr=None):
+        g = torch.Generator().manual_seed(seed)
+        K, invK = kitti_K(h, w, B)
+        if white:
+            ref = torch.randn(B, C, h, w, generator=g)
+            srcs = [torch.randn(B, C, h, w, generator=g) for _ in range(nframes)]
+        else:
+            ref = smooth_noise((B, C, h, w), g, coarse=3, lo=-1, hi=1)
+            srcs = [smooth_noise((B, C, h, w), g, coarse=3, lo=-1, hi=1) for _ in range(nframes)]
+        prior = 2 + 20 * torch.rand(B, 1, h, w, generator=g)
+        Ts = [poses(L, B, g, rot=rot, trans=trans, tz=tz)[2] for _ in range(nframes)]
+        pose = torch.stack(Ts, 1)  # B N 4 4
+        if sched == "v2":
+            hyp = L.schedule_depth_rangev2(prior, D, 0.3, type="inverse")
+        else:
+            hyp = L.schedule_depth_range_zv2(prior, D, 0.3, 30.0 * pose[:, :1, 2:3, -1:], type="inverse")
+        ref.requires_grad_(True)
+        for s in srcs:
+            s.requires_grad_(True)
+        bp, pj = L.BackprojectDepth(D, h, w), L.Project3D(D, h, w)
+        cvs = [L.generate_costvol(ref, srcs[f], K, invK, hyp, pose[:, f:f + 1], D, bp, pj) for f in range(nframes)]
+        cor, ws = _fuse_inline(cvs, G)
+        Wt = torch.randn(cor.shape, generator=g)
+        (cor * Wt).sum().backward()
+        d = dict(K=K, invK=invK, ref=ref, prior=prior, pose=pose, hyp=hyp, G=G,
+                 cor_feats=cor, grad_out=Wt, d_ref=ref.grad)
+        for f in range(nframes):
+            d["src%d" % f] = srcs[f]
+            d["d_src%d" % f] = srcs[f].grad
+            d["cor_weight%d" % f] = ws[f]
+            # grouped per-frame volume (B,D,G,h,w); the ungrouped one only for the first, small, case
+            d["grouped%d" % f] = cvs[f].reshape(B, D, -1, G, h, w).mean(2)
+        if tag == "small":
+            d["cost_vol_full0"] = cvs[0]
+        save("costvol_" + tag, d)
+
+    case("small", 201, B=2, C=32, G=16, h=8, w=16, D=6, rot=0.01, trans=0.05, tz=None)
+    case("white", 202, B=1, C=32, G=16, h=8, w=16, D=6, rot=0.01, trans=0.05, tz=None, white=True)
+    # strong motion: many taps leave the image; one sample has c_z <= 0 for near hypotheses
+    case("oob", 203, B=2, C=32, G=16, h=8, w=16, D=6, rot=0.2, trans=1.5, tz=[-3.0, 2.0])
+    case("zv2", 204, B=2, C=32, G=16, h=8, w=16, D=6, rot=0.01, trans=0.05, tz=[0.04, -0.03], sched="zv2")
+    case("twoframe", 205, B=2, C=32, G=16, h=8, w=16, D=6, rot=0.02, trans=0.1, tz=None, nframes=2)
+    case("c64g8", 206, B=1, C=64, G=8, h=6, w=10, D=5, rot=0.02, trans=0.1, tz=None)
+
+
+def gen_warp(L):
+    def case(tag, seed, rot, trans):
+        g = torch.Generator().manual_seed(seed)
+        B, H, W = 2, 16, 32
+        K, invK = kitti_K(H, W, B)
+        img = smooth_noise((B, 3, H, W), g, coarse=4)
+        depth = (2 + 20 * smooth_noise((B, 1, H, W), g, coarse=4)).requires_grad_(True)
+        aa, t, T = poses(L, B, g, rot=rot, trans=trans)
+        T = T.clone().requires_grad_(True)
+        bp, pj = L.BackprojectDepth(B, H, W), L.Project3D(B, H, W)
+        pix = pj(bp(depth, invK), K, T)
+        warped = F.grid_sample(img, pix, padding_mode="border", align_corners=True)
+        mvs_mask = ((pix < -1) | (pix > 1)).sum(-1) > 0  # trainer.py:503
+        Wt = torch.randn(warped.shape, generator=g)
+        (warped * Wt).sum().backward()
+        save("warp_" + tag, dict(K=K, invK=invK, img=img, depth=depth, T=T, pix_coords=pix, warped=warped,
+                                 mvs_mask=mvs_mask, grad_out=Wt, d_depth=depth.grad, d_T=T.grad))
+
+    case("small", 301, rot=0.01, trans=0.1)
+    case("border", 302, rot=0.1, trans=2.0)  # many samples clamp to the border (zero grid-grad there)
+
+
+def gen_ssim(L, Trainer):
+    g = torch.Generator().manual_seed(401)
+    B, H, W = 2, 16, 32
+    x = smooth_noise((B, 3, H, W), g, coarse=2).requires_grad_(True)
+    y = smooth_noise((B, 3, H, W), g, coarse=2)
+    ssim = L.SSIM()
+    s = ssim(x, y)
+    t = Trainer.__new__(Trainer)
+    t.opt = types.SimpleNamespace(no_ssim=False, ssim_lw=0.85)
+    t.ssim = ssim
+    rl = t.compute_reprojection_loss(x, y)
+    Wt = torch.randn(rl.shape, generator=g)
+    (rl * Wt).sum().backward()
+    d_pred = x.grad.clone()
+    x.grad = None
+    rl0 = t.compute_reprojection_loss(x, y, ssim_lw=0)
+    (rl0 * Wt).sum().backward()
+    # KAT5
+    ones, zeros = torch.ones(1, 3, 8, 8), torch.zeros(1, 3, 8, 8)
+    xr = torch.rand(1, 3, 8, 8, generator=g)
+    save("ssim", dict(pred=x, target=y, ssim=s, reproj=rl, grad_out=Wt, d_pred=d_pred,
+                      reproj_l1only=rl0, d_pred_l1only=x.grad,
+                      kat_same=ssim(xr, xr), kat_const=ssim(zeros, ones), kat_x=xr))
+
+
+def _make_trainer(L, Trainer, B, H, W, D=8, **flags):
+    t = Trainer.__new__(Trainer)
+    opt = dict(no_ssim=False, ssim_lw=0.85, scales=[0, 1, 2, 3], frame_ids=[0, -1, 1], height=H, width=W,
+               min_depth=0.1, max_depth=100.0, disable_automasking=False, disparity_smoothness=1e-3,
+               mask_mvs_auto=False, mask_mvs_conf=False, mask_mvs_dist=False, mask_mvs_geo=False,
+               mvs_smooth_loss=False)
+    opt.update(flags)
+    t.opt = types.SimpleNamespace(**opt)
+    t.device = torch.device("cpu")
+    t.num_scales = 4
+    t.ssim = L.SSIM()
+    t.backproject_depth = {s: L.BackprojectDepth(B, H // 2 ** s, W // 2 ** s) for s in range(4)}
+    t.project_3d = {s: L.Project3D(B, H // 2 ** s, W // 2 ** s) for s in range(4)}
+    return t
+
+
+def _inputs(B, H, W, g):
+    inputs = {}
+    for f in (0, -1, 1):
+        base = smooth_noise((B, 3, H, W), g, coarse=4)
+        for s in range(4):
+            inputs[("color", f, s)] = F.interpolate(base, size=(H // 2 ** s, W // 2 ** s), mode="bilinear",
+                                                    align_corners=False)
+            inputs[("color_aug", f, s)] = inputs[("color", f, s)]
+    for s in range(4):
+        inputs[("K", s)], inputs[("inv_K", s)] = kitti_K(H // 2 ** s, W // 2 ** s, B)
+    return inputs
+
+
+def gen_losses(L, Trainer):
+    B, H, W = 2, 32, 64
+    g = torch.Generator().manual_seed(501)
+    inputs = _inputs(B, H, W, g)
+    fx = {}
+    for (k, v) in inputs.items():
+        if k[0] in ("color", "K", "inv_K"):
+            fx["in_" + "_".join(str(x) for x in k)] = v
+    # ---- mono branch: generate_images_pred + compute_losses (trainer.py:510-532, 675-724)
+    t = _make_trainer(L, Trainer, B, H, W)
+    disps = {s: (0.004 + 0.1 * smooth_noise((B, 1, H // 2 ** s, W // 2 ** s), g, coarse=4)).requires_grad_(True)
+             for s in range(4)}
+    aa = {f: (torch.randn(B, 1, 3, generator=g) * 0.01).requires_grad_(True) for f in (-1, 1)}
+    tr = {f: (torch.randn(B, 1, 3, generator=g) * 0.05).requires_grad_(True) for f in (-1, 1)}
+    outputs = {("disp", s): disps[s] for s in range(4)}
+    for f in (-1, 1):
+        outputs[("cam_T_cam", 0, f)] = L.transformation_from_parameters(aa[f], tr[f], invert=(f < 0))
+    t.generate_images_pred(inputs, outputs)
+    torch.manual_seed(777)  # automask tie-break noise, trainer.py:698 (4 draws of (B,1,H,W), CPU generator)
+    losses = t.compute_losses(inputs, outputs)
+    losses["loss"].backward()
+    d = dict(fx)
+    d["noise_seed"] = 777
+    for s in range(4):
+        d["disp_%d" % s] = disps[s]
+        d["d_disp_%d" % s] = disps[s].grad
+        d["loss_%d" % s] = losses["loss/%d" % s]
+        d["smooth_%d" % s] = losses["mono_smooth_loss/%d" % s]
+        d["depth_0_%d" % s] = outputs[("depth", 0, s)]
+    for f in (-1, 1):
+        n = "m1" if f < 0 else "p1"
+        d["axisangle_" + n], d["translation_" + n] = aa[f], tr[f]
+        d["d_axisangle_" + n], d["d_translation_" + n] = aa[f].grad, tr[f].grad
+        d["T_" + n] = outputs[("cam_T_cam", 0, f)]
+        d["sample_%s_0" % n] = outputs[("sample", f, 0)]
+        d["color_%s_0" % n] = outputs[("color", f, 0)]
+        d["color_%s_3" % n] = outputs[("color", f, 3)]
+    d["loss"] = losses["loss"]
+    d["mono_reproj_loss"] = outputs["mono_reproj_loss"]
+    save("losses_mono", d)
+
+    # ---- mono branch without automasking
+    t2 = _make_trainer(L, Trainer, B, H, W, disable_automasking=True)
+    outputs2 = {("disp", s): disps[s].detach() for s in range(4)}
+    for f in (-1, 1):
+        outputs2[("cam_T_cam", 0, f)] = outputs[("cam_T_cam", 0, f)].detach()
+    t2.generate_images_pred(inputs, outputs2)
+    l2 = t2.compute_losses(inputs, outputs2)
+    save("losses_mono_noautomask", dict(loss=l2["loss"], **{"loss_%d" % s: l2["loss/%d" % s] for s in range(4)}))
+
+    # ---- MVS + fuse branches (trainer.py:495-508, 621-673, 569-612)
+    for tag, flags in (("default", {}), ("auto_smooth", dict(mask_mvs_auto=True, mvs_smooth_loss=True))):
+        g2 = torch.Generator().manual_seed(502)
+        t3 = _make_trainer(L, Trainer, B, H, W, **flags)
+        depth_mvs = (2 + 20 * smooth_noise((B, H, W), g2, coarse=4)).requires_grad_(True)
+        mono_depth = 2 + 20 * smooth_noise((B, 1, H, W), g2, coarse=4)
+        trust = smooth_noise((B, 1, H, W), g2, coarse=4).requires_grad_(True)
+        out3 = {"depth_mvs": depth_mvs}
+        for f in (-1, 1):
+            out3[("cam_T_cam", 0, f)] = outputs[("cam_T_cam", 0, f)].detach()
+        fused = (1 - trust) * depth_mvs[:, None].detach() + trust * mono_depth  # trainer.py:413
+        out3["fused_depth"] = fused
+        torch.manual_seed(778)
+        fuse_losses = t3.compute_fuse_losses(inputs, out3)
+        t3.generate_images_pred(inputs, out3, is_mvs=True)
+        mvs_losses = t3.compute_losses(inputs, out3, is_mvs=True)
+        (mvs_losses["loss"] + fuse_losses["loss"]).backward()
+        d3 = dict(noise_seed=778, depth_mvs=depth_mvs, mono_depth=mono_depth, trust_mono_mask=trust,
+                  T_m1=out3[("cam_T_cam", 0, -1)], T_p1=out3[("cam_T_cam", 0, 1)],
+                  mvs_loss=mvs_losses["loss"], fuse_loss=fuse_losses["loss"],
+                  fuse_reproj_loss=fuse_losses["fuse_reproj_loss"],
+                  mvs_reprojection_loss=out3["mvs_reprojection_loss"], mvs_reproj_loss=out3["mvs_reproj_loss"],
+                  mvs_color_m1=out3[("mvs_color", -1)], mvs_mask_m1=out3[("mvs_mask", -1)],
+                  mvs_color_fuse_p1=out3[("mvs_color_fuse", 1)],
+                  d_depth_mvs=depth_mvs.grad, d_trust=trust.grad)
+        if "mvs_smooth_loss/0" in mvs_losses:
+            d3["mvs_smooth_loss"] = mvs_losses["mvs_smooth_loss/0"]
+        save("losses_mvs_" + tag, d3)
+
+
+def gen_smooth(L):
+    g = torch.Generator().manual_seed(601)
+    B, H, W = 2, 12, 20
+    disp = (0.05 + 0.9 * torch.rand(B, 1, H, W, generator=g)).requires_grad_(True)
+    img = smooth_noise((B, 3, H, W), g, coarse=2)
+    mean_disp = disp.mean(2, True).mean(3, True)  # trainer.py:712-714
+    norm = disp / (mean_disp + 1e-7)
+    sl = L.get_smooth_loss(norm, img)
+    sl.backward()
+    raw = L.get_smooth_loss(disp.detach(), img)
+    save("smooth", dict(disp=disp, img=img, smooth_norm=sl, d_disp=disp.grad, smooth_raw=raw))
+
+
+def gen_postvol(L):
+    g = torch.Generator().manual_seed(701)
+    B, D, h, w = 2, 8, 6, 10
+    logits = (torch.randn(B, D, h, w, generator=g) * 2).requires_grad_(True)
+    prob = F.softmax(logits, 1)
+    prior = 2 + 20 * torch.rand(B, 1, h, w, generator=g)
+    hyp = L.schedule_depth_rangev2(prior, D, 0.3)
+    ent = L.entropy(prob, dim=1, keepdim=True)
+    dm = L.localmax(prob, 1, D, 1 / hyp[:, -1], 1 / hyp[:, 0])  # swapped endpoints, trainer.py:371 (KAT4)
+    Wd = torch.randn(dm.shape, generator=g)
+    We = torch.randn(ent.shape, generator=g)
+    ((dm * Wd).sum() + (ent * We).sum()).backward()
+    dm2 = L.localmax(prob.detach(), 2, D, 1 / hyp[:, -1], 1 / hyp[:, 0])
+    # KAT4: one-hot at d decodes to hypothesis D-1-d
+    onehot = torch.zeros(1, D, 1, D)
+    for d_ in range(D):
+        onehot[0, d_, 0, d_] = 1
+    hyp1 = hyp[:1, :, :1, :1].repeat(1, 1, 1, D)
+    kat = L.localmax(onehot, 1, D, 1 / hyp1[:, -1], 1 / hyp1[:, 0])
+    # convex upsample (layers.py:200-214), scale 2 -> 4x
+    depth = 2 + 20 * torch.rand(B, h, w, generator=g)
+    depth.requires_grad_(True)
+    mask = torch.randn(B, 16 * 9, h, w, generator=g).requires_grad_(True)
+    up = L.convex_upsample(depth, mask, 2)
+    Wu = torch.randn(up.shape, generator=g)
+    (up * Wu).sum().backward()
+    save("postvol", dict(logits=logits, hyp=hyp, entropy=ent, depth_r1=dm, depth_r2=dm2, grad_depth=Wd,
+                         grad_entropy=We, d_logits=logits.grad, kat_onehot_depth=kat, kat_hyp=hyp1,
+                         up_depth=depth, up_mask=mask, up_out=up, up_grad=Wu, d_up_depth=depth.grad,
+                         d_up_mask=mask.grad))
+
+
+def main():
+    torch.set_num_threads(1)
+    L, Trainer, _ = load_reference(with_trainer=True)
+    gen_geometry(L)
+    gen_schedule(L)
+    gen_costvol(L)
+    gen_warp(L)
+    gen_ssim(L, Trainer)
+    gen_losses(L, Trainer)
+    gen_smooth(L)
+    gen_postvol(L)
+
+
+if __name__ == "__main__":
+    main()
