@@ -1,0 +1,152 @@
+/*
+ * movedepth_hip.h -- C ABI of libmovedepth_hip.so (MI355X / gfx950).
+ *
+ * The drop-in boundary for MOVEDepth's cost-volume + photometric-loss training hot path
+ * (SURVEY.md section 8b).  The reference has no FFI layer: its "operator API" is the Python
+ * signatures in movedepth/layers.py and movedepth/trainer.py.  Each entry point below names the
+ * reference code it replaces (paths relative to /root/reference/movedepth/); the Python host
+ * (movedepth_amd/layers.py, ops.py) binds these with ctypes and keeps the reference signatures.
+ *
+ * Conventions
+ *   - plain C symbols; every pointer is a DEVICE pointer owned by the caller, never retained or freed;
+ *   - all tensors are contiguous row-major float32 unless a stride argument says otherwise;
+ *   - no hidden allocation: scratch is passed in (`ws`, size from the matching *_ws_bytes());
+ *   - asynchronous: work is enqueued on `stream` (a hipStream_t; NULL = default stream); re-entrant
+ *     across streams;
+ *   - return 0 on success, a negative MD_E* code otherwise; md_last_error() gives the message of the
+ *     last failure on the calling thread.
+ */
+#ifndef MOVEDEPTH_HIP_H
+#define MOVEDEPTH_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *md_stream_t; /* hipStream_t */
+
+#define MD_OK 0
+#define MD_EINVAL (-1)   /* bad argument / unsupported shape */
+#define MD_ELAUNCH (-2)  /* HIP launch or runtime error      */
+
+const char *md_last_error(void);
+/* ABI version of this header; bumped on any signature change. */
+int md_abi_version(void);
+
+/* depth-range schedule types (layers.py:264-279 `type`) */
+#define MD_SCHED_INVERSE 0
+#define MD_SCHED_LINEAR 1
+#define MD_SCHED_LOG 2
+
+/* ---- depth-range sampling ---------------------------------------------------------------
+ * schedule_depth_rangev2 (layers.py:256-284) when ztrans == NULL,
+ * schedule_depth_range_zv2 (layers.py:370-398) otherwise, with ztrans[b] = z_scale*T[b,2,3]
+ * (trainer.py:340; one lookup frame).  prior [B,1,h,w] -> out [B,D,h,w].  no_grad in the reference. */
+int md_schedule_depth_range(const float *prior, const float *ztrans, int B, int h, int w, int D, float scale_fac,
+                            int type, float *out, md_stream_t stream);
+
+/* ---- plane-sweep cost volume ------------------------------------------------------------
+ * generate_costvol (layers.py:778-794: BackprojectDepth 581-586, Project3D 608-620, grid_sample zeros /
+ * bilinear / align_corners=True, x ref) fused with the group mean of trainer.py:359
+ * (group g = mean of channels {g, g+G, ...}).  G == C gives the reference's ungrouped (B,D,C,h,w) volume.
+ *
+ *   ref, src [B,C,h,w]; K, invK, pose [B,4,4] (scale-`prior_scale` intrinsics, pose = pose[:,0]);
+ *   hypotheses: either hyp [B,D,h,w], or hyp == NULL and the schedule fused in from
+ *   prior [B,1,h,w] (+ ztrans/scale_fac/sched_type as in md_schedule_depth_range; same arithmetic).
+ *   out element (b,d,g,y,x) is written at out[b*out_sb + d*out_sd + g*out_sg + y*w + x]
+ *   (strides in floats), so the volume can be laid out (B,D,G,h,w) like the reference or (B,G,D,h,w)
+ *   as the 3-D regulariser consumes it (resnet_encoder.py:257) without a permute copy.
+ */
+int md_costvol_fwd(const float *ref, const float *src, const float *K, const float *invK, const float *pose,
+                   const float *hyp, const float *prior, const float *ztrans, float scale_fac, int sched_type,
+                   int B, int C, int G, int h, int w, int D, float *out, long long out_sb, long long out_sd,
+                   long long out_sg, md_stream_t stream);
+
+/* Autograd of md_costvol_fwd w.r.t. ref and src (the sampling grid is under no_grad, layers.py:784).
+ * gout addressed with the same three strides; d_ref, d_src [B,C,h,w] are overwritten. */
+int md_costvol_bwd(const float *gout, long long g_sb, long long g_sd, long long g_sg, const float *ref,
+                   const float *src, const float *K, const float *invK, const float *pose, const float *hyp,
+                   const float *prior, const float *ztrans, float scale_fac, int sched_type, int B, int C, int G,
+                   int h, int w, int D, float *d_ref, float *d_src, md_stream_t stream);
+
+/* ---- frame-confidence fusion --------------------------------------------------------------
+ * trainer.py:349-363: w_f = max_G softmax_G(mean_D vol_f); out = sum_f w_f vol_f / (1e-8 + sum_f w_f).
+ * vols: N device pointers (host array) to grouped volumes addressed with (sb, sd, sg) strides, as is out.
+ * weights [N,B,h,w] may be NULL. */
+int md_fuse_fwd(const float *const *vols, int N, int B, int D, int G, int hw, long long sb, long long sd,
+                long long sg, float *out, float *weights, md_stream_t stream);
+/* Autograd of md_fuse_fwd (the weights are not detached in the reference). d_vols: N pointers. */
+int md_fuse_bwd(const float *gout, const float *const *vols, int N, int B, int D, int G, int hw, long long sb,
+                long long sd, long long sg, float *const *d_vols, md_stream_t stream);
+
+/* ---- reprojection warp ----------------------------------------------------------------------
+ * generate_images_pred / compute_fuse_losses warp (trainer.py:501-507, 519-529, 575-580):
+ * BackprojectDepth[0] -> Project3D[0] -> grid_sample(padding_mode='border', align_corners=True).
+ * img [B,Ci,H,W]; depth [B,1,H,W]; K, invK, T [B,4,4].  pix [B,H,W,2] (normalised grid, may be NULL),
+ * out [B,Ci,H,W], oob_mask [B,H,W] uint8 (any coordinate outside [-1,1], trainer.py:503; may be NULL). */
+int md_warp_fwd(const float *img, const float *depth, const float *K, const float *invK, const float *T, int B,
+                int Ci, int H, int W, float *pix, float *out, unsigned char *oob_mask, md_stream_t stream);
+/* Gradients to depth [B,1,H,W] and T [B,4,4].  ws: md_warp_bwd_ws_bytes(B,H,W) bytes. */
+size_t md_warp_bwd_ws_bytes(int B, int H, int W);
+int md_warp_bwd(const float *gout, const float *img, const float *depth, const float *K, const float *invK,
+                const float *T, int B, int Ci, int H, int W, float *d_depth, float *d_T, void *ws,
+                md_stream_t stream);
+
+/* Disparity pyramid level -> full-resolution depth: F.interpolate(bilinear, align_corners=False)
+ * (trainer.py:512) followed by disp_to_depth (layers.py:400-409).  disp [B,1,h,w] -> depth [B,1,H,W]. */
+int md_disp_to_depth_up_fwd(const float *disp, int B, int h, int w, int H, int W, float min_depth, float max_depth,
+                            float *depth, md_stream_t stream);
+int md_disp_to_depth_up_bwd(const float *g_depth, const float *disp, int B, int h, int w, int H, int W,
+                            float min_depth, float max_depth, float *d_disp, md_stream_t stream);
+
+/* ---- SSIM + L1 reprojection loss ----------------------------------------------------------
+ * compute_reprojection_loss (trainer.py:535-550) with SSIM.forward (layers.py:663-677):
+ * out = ssim_w * mean_c SSIM(pred,target) + (1-ssim_w) * mean_c |target - pred|; no_ssim -> L1 only.
+ * pred, target [B,C,H,W] -> out [B,1,H,W].  md_ssim: the bare SSIM map [B,C,H,W]. */
+int md_ssim(const float *x, const float *y, int B, int C, int H, int W, float *out, md_stream_t stream);
+int md_reproj_loss_fwd(const float *pred, const float *target, int B, int C, int H, int W, float ssim_w, int no_ssim,
+                       float *out, md_stream_t stream);
+int md_reproj_loss_bwd(const float *gout, const float *pred, const float *target, int B, int C, int H, int W,
+                       float ssim_w, int no_ssim, float *d_pred, md_stream_t stream);
+
+/* ---- min over frames / auto-mask / masked mean ------------------------------------------
+ * trainer.py:687-709 (mono) and 630-662 (MVS).  reproj, ident [B,N,H,W] (ident NULL = no automask);
+ * noise [B,1,H,W] already scaled by 1e-5 (trainer.py:698), may be NULL; ext_mask [B,1,H,W] may be NULL;
+ * mvs_mode != 0 replaces the automask by ones (trainer.py:647).
+ * Outputs: min_reproj, mask [B,1,H,W]; loss[0] = sum(min*mask) / (sum(mask) + 1e-7); loss[1] = sum(mask).
+ * ws: md_masked_min_ws_bytes(B,H,W) bytes. */
+size_t md_masked_min_ws_bytes(int B, int H, int W);
+int md_masked_min_fwd(const float *reproj, const float *ident, const float *noise, const float *ext_mask, int B,
+                      int N, int H, int W, int mvs_mode, float *min_reproj, float *mask, float *loss, void *ws,
+                      md_stream_t stream);
+/* d loss / d reproj [B,N,H,W]; gloss: device scalar; loss: the [2] array written by the forward. */
+int md_masked_min_bwd(const float *gloss, const float *reproj, const float *mask, const float *loss, int B, int N,
+                      int H, int W, float *d_reproj, md_stream_t stream);
+
+/* ---- edge-aware smoothness ---------------------------------------------------------------
+ * get_smooth_loss (layers.py:630-643) on disp / (mean_hw(disp) + 1e-7) (trainer.py:712-714) when
+ * normalize != 0.  disp [B,1,h,w]; img [B,Ci,h,w]; loss: device scalar.
+ * ws: md_smooth_ws_bytes(B,h,w) bytes, shared by forward and backward of one call pair. */
+size_t md_smooth_ws_bytes(int B, int h, int w);
+int md_smooth_fwd(const float *disp, const float *img, int B, int Ci, int h, int w, int normalize, float *loss,
+                  void *ws, md_stream_t stream);
+int md_smooth_bwd(const float *gloss, const float *disp, const float *img, int B, int Ci, int h, int w,
+                  int normalize, float *d_disp, void *ws, md_stream_t stream);
+
+/* ---- post-volume ops ("next" rows) --------------------------------------------
+ * Fused softmax over D (trainer.py:367) + entropy (layers.py:862-863) + localmax (layers.py:796-812).
+ * logits [B,D,h,w]; min_inv, max_inv [B,h,w] (the caller passes 1/hyp[:,-1], 1/hyp[:,0], trainer.py:371).
+ * Outputs: prob [B,D,h,w] (may be NULL), entropy [B,1,h,w] (may be NULL), depth [B,h,w]. */
+int md_softmax_entropy_localmax_fwd(const float *logits, int B, int D, int h, int w, int radius,
+                                    const float *min_inv, const float *max_inv, float *prob, float *entropy,
+                                    float *depth, md_stream_t stream);
+int md_softmax_entropy_localmax_bwd(const float *g_depth, const float *g_entropy, const float *logits, int B, int D,
+                                    int h, int w, int radius, const float *min_inv, const float *max_inv,
+                                    float *d_logits, md_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MOVEDEPTH_HIP_H */

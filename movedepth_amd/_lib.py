@@ -1,0 +1,80 @@
+"""ctypes binding of libmovedepth_hip.so (the C ABI declared in include/movedepth_hip.h).
+
+There is no CPU fallback: if the library is missing or a call fails this raises.  Build it with
+`python -c "import __graft_entry__ as g; g.build()"` or `make -C movedepth_amd/csrc`.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmovedepth_hip.so")
+
+_vp = ctypes.c_void_p
+_i = ctypes.c_int
+_f = ctypes.c_float
+_ll = ctypes.c_longlong
+_sz = ctypes.c_size_t
+
+# name -> (restype, argtypes); must list every symbol the header declares (tests/test_cabi.py checks)
+SIGNATURES = {
+    "md_last_error": (ctypes.c_char_p, []),
+    "md_abi_version": (_i, []),
+    "md_schedule_depth_range": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp]),
+    "md_costvol_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _i, _i, _i, _vp, _ll, _ll,
+                           _ll, _vp]),
+    "md_costvol_bwd": (_i, [_vp, _ll, _ll, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _i, _i,
+                           _i, _vp, _vp, _vp]),
+    "md_fuse_fwd": (_i, [_vp, _i, _i, _i, _i, _i, _ll, _ll, _ll, _vp, _vp, _vp]),
+    "md_fuse_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _ll, _ll, _ll, _vp, _vp]),
+    "md_warp_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "md_warp_bwd_ws_bytes": (_sz, [_i, _i, _i]),
+    "md_warp_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "md_disp_to_depth_up_fwd": (_i, [_vp, _i, _i, _i, _i, _i, _f, _f, _vp, _vp]),
+    "md_disp_to_depth_up_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _f, _vp, _vp]),
+    "md_ssim": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "md_reproj_loss_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp]),
+    "md_reproj_loss_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp]),
+    "md_masked_min_ws_bytes": (_sz, [_i, _i, _i]),
+    "md_masked_min_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "md_masked_min_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "md_smooth_ws_bytes": (_sz, [_i, _i, _i]),
+    "md_smooth_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "md_smooth_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "md_softmax_entropy_localmax_fwd": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "md_softmax_entropy_localmax_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+class MovedepthHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Loads the library once; raises (never falls back) when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MovedepthHipError(
+            "libmovedepth_hip.so not found at %s: the HIP extension is required (no CPU fallback). "
+            "Build it with `make -C movedepth_amd/csrc` (hipcc --offload-arch=gfx950)." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so is stale
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, name):
+    if rc != 0:
+        msg = load().md_last_error()
+        raise MovedepthHipError("%s failed (%d): %s" % (name, rc, msg.decode() if msg else "?"))
+
+
+def call(name, *args):
+    """Invoke an int-returning entry point and raise on a non-zero status."""
+    check(getattr(load(), name)(*args), name)

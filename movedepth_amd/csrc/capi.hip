@@ -1,0 +1,42 @@
+// Error plumbing + the small standalone kernels of the C ABI (schedule).
+#include <string.h>
+
+#include "md_common.hpp"
+
+static thread_local char g_err[512] = "";
+
+void md_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char *md_last_error(void) { return g_err; }
+extern "C" int md_abi_version(void) { return 1; }
+
+namespace {
+
+// schedule_depth_rangev2 / _zv2 (reference layers.py:256-284, 370-398): one thread per (b, k, pixel)
+__global__ __launch_bounds__(256) void schedule_kernel(const float *__restrict__ prior, const float *__restrict__ ztrans,
+                                                       int hw, int D, float scale_fac, int type, float *__restrict__ out) {
+    const int b = blockIdx.z, k = blockIdx.y;
+    const float one_pf = 1.f + (ztrans ? scale_fac * ztrans[b] : scale_fac);
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < hw; p += gridDim.x * 256)
+        out[((size_t)b * D + k) * hw + p] = md_hypothesis(prior[(size_t)b * hw + p], one_pf, k, D, type);
+}
+
+}  // namespace
+
+extern "C" int md_schedule_depth_range(const float *prior, const float *ztrans, int B, int h, int w, int D,
+                                       float scale_fac, int type, float *out, md_stream_t stream) {
+    MD_REQUIRE(prior && out, "md_schedule_depth_range: null tensor");
+    MD_REQUIRE(B > 0 && h > 0 && w > 0 && D > 1, "md_schedule_depth_range: bad dims B=%d h=%d w=%d D=%d", B, h, w, D);
+    MD_REQUIRE(type >= 0 && type <= 2, "md_schedule_depth_range: bad type %d", type);
+    MD_REQUIRE(D <= 65535 && B <= 65535, "md_schedule_depth_range: D/B too large");
+    const int hw = h * w;
+    dim3 grid(md_cdiv(hw, 256) < 64 ? md_cdiv(hw, 256) : 64, D, B);
+    hipLaunchKernelGGL(schedule_kernel, grid, dim3(256), 0, (hipStream_t)stream, prior, ztrans, hw, D, scale_fac, type, out);
+    MD_CHECK_LAUNCH("md_schedule_depth_range");
+    return MD_OK;
+}

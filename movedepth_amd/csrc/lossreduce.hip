@@ -1,0 +1,235 @@
+// Loss reductions of the photometric path:
+//   * min over frames + auto-mask + masked mean (reference trainer.py:687-709 mono, 630-662 MVS,
+//     compute_loss_masks 552-567),
+//   * edge-aware smoothness on the mean-normalised disparity (layers.py:630-643, trainer.py:712-714).
+// All reductions are two-stage and deterministic (per-block partials in the caller's workspace, then a
+// single-block finish); no float atomics.  Launch-latency-bound on (B,1,H,W) maps.
+#include "md_common.hpp"
+
+namespace {
+
+__device__ __forceinline__ float block_sum(float v, float *red /*[4]*/) {
+    v = md_wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+// ------------------------------------------------------------------ masked min
+__global__ __launch_bounds__(256) void masked_min_kernel(const float *__restrict__ reproj, const float *__restrict__ ident,
+                                                         const float *__restrict__ noise, const float *__restrict__ ext,
+                                                         int N, int HW, int total, int mvs_mode,
+                                                         float *__restrict__ mn, float *__restrict__ mask,
+                                                         float *__restrict__ ws) {
+    __shared__ float red[4];
+    float num = 0.f, den = 0.f;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int b = i / HW, p = i % HW;
+        const float *rp = reproj + (size_t)b * N * HW + p;
+        float r = rp[0];
+        for (int f = 1; f < N; ++f) r = fminf(r, rp[(size_t)f * HW]);
+        float m = 1.f;
+        if (ident && !mvs_mode) {
+            const float *ip = ident + (size_t)b * N * HW + p;
+            float id = ip[0];
+            for (int f = 1; f < N; ++f) id = fminf(id, ip[(size_t)f * HW]);
+            if (noise) id += noise[i];
+            m = (r <= id) ? 1.f : 0.f;  // argmin([reproj, identity]) == 0, first index wins ties
+        }
+        if (ext) m *= ext[i];
+        mn[i] = r;
+        mask[i] = m;
+        num += r * m;
+        den += m;
+    }
+    num = block_sum(num, red);
+    den = block_sum(den, red);
+    if (threadIdx.x == 0) { ws[blockIdx.x * 2] = num; ws[blockIdx.x * 2 + 1] = den; }
+}
+
+__global__ __launch_bounds__(256) void masked_min_finish_kernel(const float *__restrict__ ws, int nblk, float *__restrict__ loss) {
+    __shared__ float red[4];
+    float num = 0.f, den = 0.f;
+    for (int k = threadIdx.x; k < nblk; k += 256) { num += ws[k * 2]; den += ws[k * 2 + 1]; }
+    num = block_sum(num, red);
+    den = block_sum(den, red);
+    if (threadIdx.x == 0) { loss[0] = num / (den + 1e-7f); loss[1] = den; }
+}
+
+__global__ __launch_bounds__(256) void masked_min_bwd_kernel(const float *__restrict__ gloss, const float *__restrict__ reproj,
+                                                             const float *__restrict__ mask, const float *__restrict__ loss,
+                                                             int N, int HW, int total, float *__restrict__ d_reproj) {
+    const float scale = gloss[0] / (loss[1] + 1e-7f);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int b = i / HW, p = i % HW;
+        const float *rp = reproj + (size_t)b * N * HW + p;
+        int am = 0;
+        float r = rp[0];
+        for (int f = 1; f < N; ++f) {
+            const float v = rp[(size_t)f * HW];
+            if (v < r) { r = v; am = f; }
+        }
+        const float g = scale * mask[i];
+        for (int f = 0; f < N; ++f) d_reproj[((size_t)b * N + f) * HW + p] = f == am ? g : 0.f;
+    }
+}
+
+int mm_blocks(int total) {
+    int n = md_cdiv(total, 256 * 4);
+    return n < 1 ? 1 : (n > 1024 ? 1024 : n);
+}
+
+// ------------------------------------------------------------------ smoothness
+constexpr int SM_BLK = 64;  // blocks per sample for the pixel passes
+
+// workspace layout (floats): mean[B] | part[B*SM_BLK*2] | dots[B*SM_BLK]
+__global__ __launch_bounds__(256) void smooth_mean_kernel(const float *__restrict__ disp, int hw, float *__restrict__ ws) {
+    __shared__ float red[4];
+    const int b = blockIdx.x;
+    float s = 0.f;
+    for (int p = threadIdx.x; p < hw; p += 256) s += disp[(size_t)b * hw + p];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) ws[b] = s / (float)hw;
+}
+
+__device__ __forceinline__ float edge_w(const float *__restrict__ img, int Ci, size_t hw, size_t p, size_t q) {
+    float gi = 0.f;
+    for (int c = 0; c < Ci; ++c) gi += fabsf(img[c * hw + p] - img[c * hw + q]);
+    return expf(-gi / (float)Ci);
+}
+
+__global__ __launch_bounds__(256) void smooth_fwd_kernel(const float *__restrict__ disp, const float *__restrict__ img,
+                                                         int Ci, int h, int w, int normalize, int B, float *__restrict__ ws) {
+    __shared__ float red[4];
+    const int b = blockIdx.y, hw = h * w;
+    const float dn = normalize ? ws[b] + 1e-7f : 1.f;
+    const float *d = disp + (size_t)b * hw, *im = img + (size_t)b * Ci * hw;
+    float sx = 0.f, sy = 0.f;
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < hw; p += SM_BLK * 256) {
+        const int x = p % w, y = p / w;
+        const float a = d[p] / dn;
+        if (x + 1 < w) sx += fabsf(a - d[p + 1] / dn) * edge_w(im, Ci, hw, p, p + 1);
+        if (y + 1 < h) sy += fabsf(a - d[p + w] / dn) * edge_w(im, Ci, hw, p, p + w);
+    }
+    sx = block_sum(sx, red);
+    sy = block_sum(sy, red);
+    if (threadIdx.x == 0) {
+        float *part = ws + B + ((size_t)b * SM_BLK + blockIdx.x) * 2;
+        part[0] = sx; part[1] = sy;
+    }
+}
+
+__global__ __launch_bounds__(256) void smooth_finish_kernel(const float *__restrict__ ws, int B, int h, int w, float *__restrict__ loss) {
+    __shared__ float red[4];
+    float sx = 0.f, sy = 0.f;
+    for (int k = threadIdx.x; k < B * SM_BLK; k += 256) { sx += ws[B + k * 2]; sy += ws[B + k * 2 + 1]; }
+    sx = block_sum(sx, red);
+    sy = block_sum(sy, red);
+    if (threadIdx.x == 0) loss[0] = sx / ((float)B * h * (w - 1)) + sy / ((float)B * (h - 1) * w);
+}
+
+// pass 1 of the backward: gn = dL/d(normalised disp) (gather form) into d_disp, and per-block dot(gn, disp)
+__global__ __launch_bounds__(256) void smooth_bwd_kernel(const float *__restrict__ gloss, const float *__restrict__ disp,
+                                                         const float *__restrict__ img, int Ci, int h, int w, int normalize,
+                                                         int B, float *__restrict__ d_disp, float *__restrict__ ws) {
+    __shared__ float red[4];
+    const int b = blockIdx.y, hw = h * w;
+    const float dn = normalize ? ws[b] + 1e-7f : 1.f;
+    const float cx = gloss[0] / ((float)B * h * (w - 1)), cy = gloss[0] / ((float)B * (h - 1) * w);
+    const float *d = disp + (size_t)b * hw, *im = img + (size_t)b * Ci * hw;
+    float dot = 0.f;
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < hw; p += SM_BLK * 256) {
+        const int x = p % w, y = p / w;
+        const float a = d[p] / dn;
+        float g = 0.f;
+        if (x + 1 < w) { const float df = a - d[p + 1] / dn; g += (df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f)) * edge_w(im, Ci, hw, p, p + 1) * cx; }
+        if (x > 0)     { const float df = d[p - 1] / dn - a; g -= (df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f)) * edge_w(im, Ci, hw, p - 1, p) * cx; }
+        if (y + 1 < h) { const float df = a - d[p + w] / dn; g += (df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f)) * edge_w(im, Ci, hw, p, p + w) * cy; }
+        if (y > 0)     { const float df = d[p - w] / dn - a; g -= (df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f)) * edge_w(im, Ci, hw, p - w, p) * cy; }
+        d_disp[(size_t)b * hw + p] = g;
+        dot += g * d[p];
+    }
+    dot = block_sum(dot, red);
+    if (threadIdx.x == 0) ws[B + (size_t)B * SM_BLK * 2 + (size_t)b * SM_BLK + blockIdx.x] = dot;
+}
+
+// pass 2: nd = d / (mean + 1e-7)  =>  d_d[q] = gn[q]/dn - dot/(dn^2 hw)
+__global__ __launch_bounds__(256) void smooth_bwd_finish_kernel(int hw, int B, float *__restrict__ d_disp, const float *__restrict__ ws) {
+    const int b = blockIdx.y;
+    const float dn = ws[b] + 1e-7f;
+    float dot = 0.f;
+    for (int k = 0; k < SM_BLK; ++k) dot += ws[B + (size_t)B * SM_BLK * 2 + (size_t)b * SM_BLK + k];
+    const float corr = dot / (dn * dn) / (float)hw;
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < hw; p += SM_BLK * 256)
+        d_disp[(size_t)b * hw + p] = d_disp[(size_t)b * hw + p] / dn - corr;
+}
+
+}  // namespace
+
+extern "C" size_t md_masked_min_ws_bytes(int B, int H, int W) { return sizeof(float) * 2 * (size_t)mm_blocks(B * H * W); }
+
+extern "C" int md_masked_min_fwd(const float *reproj, const float *ident, const float *noise, const float *ext_mask,
+                                 int B, int N, int H, int W, int mvs_mode, float *min_reproj, float *mask, float *loss,
+                                 void *ws, md_stream_t stream) {
+    MD_REQUIRE(reproj && min_reproj && mask && loss && ws, "md_masked_min_fwd: null tensor");
+    MD_REQUIRE(B > 0 && N > 0 && H > 0 && W > 0, "md_masked_min_fwd: bad dims");
+    const int total = B * H * W, nblk = mm_blocks(total);
+    hipLaunchKernelGGL(masked_min_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, reproj, ident, noise, ext_mask, N,
+                       H * W, total, mvs_mode, min_reproj, mask, (float *)ws);
+    MD_CHECK_LAUNCH("md_masked_min_fwd");
+    hipLaunchKernelGGL(masked_min_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float *)ws, nblk, loss);
+    MD_CHECK_LAUNCH("md_masked_min_fwd(finish)");
+    return MD_OK;
+}
+
+extern "C" int md_masked_min_bwd(const float *gloss, const float *reproj, const float *mask, const float *loss, int B,
+                                 int N, int H, int W, float *d_reproj, md_stream_t stream) {
+    MD_REQUIRE(gloss && reproj && mask && loss && d_reproj, "md_masked_min_bwd: null tensor");
+    MD_REQUIRE(B > 0 && N > 0 && H > 0 && W > 0, "md_masked_min_bwd: bad dims");
+    const int total = B * H * W;
+    hipLaunchKernelGGL(masked_min_bwd_kernel, dim3(mm_blocks(total)), dim3(256), 0, (hipStream_t)stream, gloss, reproj, mask,
+                       loss, N, H * W, total, d_reproj);
+    MD_CHECK_LAUNCH("md_masked_min_bwd");
+    return MD_OK;
+}
+
+extern "C" size_t md_smooth_ws_bytes(int B, int h, int w) {
+    (void)h; (void)w;
+    return sizeof(float) * ((size_t)B + (size_t)B * SM_BLK * 3);
+}
+
+extern "C" int md_smooth_fwd(const float *disp, const float *img, int B, int Ci, int h, int w, int normalize, float *loss,
+                             void *ws, md_stream_t stream) {
+    MD_REQUIRE(disp && img && loss && ws, "md_smooth_fwd: null tensor");
+    MD_REQUIRE(B > 0 && B <= 65535 && Ci > 0 && h > 1 && w > 1, "md_smooth_fwd: bad dims");
+    if (normalize) {
+        hipLaunchKernelGGL(smooth_mean_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, disp, h * w, (float *)ws);
+        MD_CHECK_LAUNCH("md_smooth_fwd(mean)");
+    }
+    hipLaunchKernelGGL(smooth_fwd_kernel, dim3(SM_BLK, B), dim3(256), 0, (hipStream_t)stream, disp, img, Ci, h, w, normalize,
+                       B, (float *)ws);
+    MD_CHECK_LAUNCH("md_smooth_fwd");
+    hipLaunchKernelGGL(smooth_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float *)ws, B, h, w, loss);
+    MD_CHECK_LAUNCH("md_smooth_fwd(finish)");
+    return MD_OK;
+}
+
+extern "C" int md_smooth_bwd(const float *gloss, const float *disp, const float *img, int B, int Ci, int h, int w,
+                             int normalize, float *d_disp, void *ws, md_stream_t stream) {
+    MD_REQUIRE(gloss && disp && img && d_disp && ws, "md_smooth_bwd: null tensor");
+    MD_REQUIRE(B > 0 && B <= 65535 && Ci > 0 && h > 1 && w > 1, "md_smooth_bwd: bad dims");
+    if (normalize) {  // recompute the means: the workspace need not survive between forward and backward
+        hipLaunchKernelGGL(smooth_mean_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, disp, h * w, (float *)ws);
+        MD_CHECK_LAUNCH("md_smooth_bwd(mean)");
+    }
+    hipLaunchKernelGGL(smooth_bwd_kernel, dim3(SM_BLK, B), dim3(256), 0, (hipStream_t)stream, gloss, disp, img, Ci, h, w,
+                       normalize, B, d_disp, (float *)ws);
+    MD_CHECK_LAUNCH("md_smooth_bwd");
+    if (normalize) {
+        hipLaunchKernelGGL(smooth_bwd_finish_kernel, dim3(SM_BLK, B), dim3(256), 0, (hipStream_t)stream, h * w, B, d_disp,
+                           (const float *)ws);
+        MD_CHECK_LAUNCH("md_smooth_bwd(finish)");
+    }
+    return MD_OK;
+}

@@ -1,0 +1,149 @@
+// Shared host/device helpers for libmovedepth_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "../../include/movedepth_hip.h"
+
+// ---------------------------------------------------------------- error plumbing
+void md_set_error(const char *fmt, ...);
+
+#define MD_REQUIRE(cond, ...)         \
+    do {                              \
+        if (!(cond)) {                \
+            md_set_error(__VA_ARGS__); \
+            return MD_EINVAL;         \
+        }                             \
+    } while (0)
+
+#define MD_CHECK_LAUNCH(name)                                                   \
+    do {                                                                        \
+        hipError_t e_ = hipGetLastError();                                      \
+        if (e_ != hipSuccess) {                                                 \
+            md_set_error("%s: launch failed: %s", name, hipGetErrorString(e_)); \
+            return MD_ELAUNCH;                                                  \
+        }                                                                       \
+    } while (0)
+
+#define MD_CHECK_HIP(expr)                                                    \
+    do {                                                                      \
+        hipError_t e_ = (expr);                                               \
+        if (e_ != hipSuccess) {                                               \
+            md_set_error("%s failed: %s", #expr, hipGetErrorString(e_));      \
+            return MD_ELAUNCH;                                                \
+        }                                                                     \
+    } while (0)
+
+static inline int md_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// ---------------------------------------------------------------- geometry (device)
+// Per-sample camera constants, wave-uniform (live in SGPRs).
+struct CamMats {
+    float P[12];  // (K @ T)[:3,:]          layers.py:608
+    float iK[9];  // inv_K[:3,:3]           layers.py:582
+};
+
+__device__ __forceinline__ CamMats md_load_cam(const float *__restrict__ K, const float *__restrict__ invK,
+                                               const float *__restrict__ T) {
+    CamMats m;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s += K[i * 4 + k] * T[k * 4 + j];
+            m.P[i * 4 + j] = s;
+        }
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) m.iK[i * 3 + j] = invK[i * 4 + j];
+    return m;
+}
+
+// Ray through pixel (x, y): inv_K[:3,:3] @ (x, y, 1)
+__device__ __forceinline__ void md_ray(const CamMats &m, float x, float y, float &r0, float &r1, float &r2) {
+    r0 = m.iK[0] * x + m.iK[1] * y + m.iK[2];
+    r1 = m.iK[3] * x + m.iK[4] * y + m.iK[5];
+    r2 = m.iK[6] * x + m.iK[7] * y + m.iK[8];
+}
+
+// Backproject at depth d and project: returns the un-normalised sample position (ix, iy) grid_sample uses,
+// following the reference's operation order (layers.py:583, 610-620, then grid_sample's un-normalise).
+struct Proj {
+    float ix, iy;  // sample position in source pixels (before any border clipping)
+    float gx, gy;  // normalised grid coordinates in [-1,1]
+    float u, v, zz;
+    float X, Y, Z;
+};
+
+__device__ __forceinline__ Proj md_project(const CamMats &m, float r0, float r1, float r2, float d, int w, int h) {
+    Proj p;
+    p.X = d * r0;
+    p.Y = d * r1;
+    p.Z = d * r2;
+    float c0 = m.P[0] * p.X + m.P[1] * p.Y + m.P[2] * p.Z + m.P[3];
+    float c1 = m.P[4] * p.X + m.P[5] * p.Y + m.P[6] * p.Z + m.P[7];
+    float c2 = m.P[8] * p.X + m.P[9] * p.Y + m.P[10] * p.Z + m.P[11];
+    p.zz = c2 + 1e-7f;
+    p.u = c0 / p.zz;
+    p.v = c1 / p.zz;
+    p.gx = (p.u / (float)(w - 1) - 0.5f) * 2.f;
+    p.gy = (p.v / (float)(h - 1) - 0.5f) * 2.f;
+    p.ix = ((p.gx + 1.f) / 2.f) * (float)(w - 1);
+    p.iy = ((p.gy + 1.f) / 2.f) * (float)(h - 1);
+    return p;
+}
+
+// Depth hypothesis k of D for prior depth c (layers.py:261-279 / 375-393).  one_pf = 1 + scale_fac[*ztrans].
+__device__ __forceinline__ float md_hypothesis(float c, float one_pf, int k, int D, int type) {
+    float dmin = c / one_pf, dmax = c * one_pf;
+    if (type == MD_SCHED_INVERSE) {
+        float itv = (float)k / (float)(D - 1);
+        float inv = 1.f / dmax + (1.f / dmin - 1.f / dmax) * itv;
+        return 1.f / inv;
+    }
+    float itv = (type == MD_SCHED_LOG) ? expf(logf(0.1f) + logf(1.f / 0.1f) * (float)k / (float)(D - 1))
+                                       : (float)k / (float)(D - 1);
+    return dmin + (dmax - dmin) * itv;
+}
+
+// Bilinear tap set.  x0,y0 = north-west tap; wx1, wy1 = weights of the east / south taps.
+struct Tap {
+    int x0, y0;
+    float wx1, wy1;
+};
+
+__device__ __forceinline__ Tap md_make_tap(float ix, float iy, int w, int h) {
+    Tap t;
+    float fx = floorf(ix), fy = floorf(iy);
+    t.wx1 = ix - fx;
+    t.wy1 = iy - fy;
+    // keep the int conversion defined for wild coordinates (those taps are out of range anyway)
+    bool bad = !(ix == ix) || !(iy == iy);
+    fx = fminf(fmaxf(fx, -2.f), (float)w);
+    fy = fminf(fmaxf(fy, -2.f), (float)h);
+    t.x0 = bad ? -2 : (int)fx;
+    t.y0 = bad ? -2 : (int)fy;
+    if (bad) { t.wx1 = 0.f; t.wy1 = 0.f; }
+    return t;
+}
+
+// ---------------------------------------------------------------- reductions
+__device__ __forceinline__ float md_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ int md_wave_min(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ int md_wave_max(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+    return v;
+}

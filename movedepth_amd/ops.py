@@ -1,0 +1,372 @@
+"""torch.autograd.Function wrappers over the C ABI (include/movedepth_hip.h).
+
+PyTorch is plumbing here: it owns device memory, the current HIP stream and autograd bookkeeping; every
+forward/backward below is one or two launches of a hand-written gfx950 kernel.  No CPU fallback exists:
+tensors must live on the GPU and the HIP library must load, otherwise these raise.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+_TYPES = {"inverse": 0, "linear": 1, "log": 2}
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _prep(t, name):
+    """float32, contiguous, on the GPU -- or raise (never silently move work to the CPU)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise _lib.MovedepthHipError("%s must be a GPU tensor (got %s): the HIP path has no CPU fallback" % (name, t.device))
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def _ws(nbytes, device):
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+
+# --------------------------------------------------------------------------- schedule
+def schedule_depth_range(prior_depth, ndepth, scale_fac, z_trans=None, type="inverse"):
+    """schedule_depth_rangev2 / schedule_depth_range_zv2 (reference layers.py:256-284 / 370-398). no_grad."""
+    if type not in _TYPES:
+        raise NotImplementedError(type)
+    with torch.no_grad():
+        prior = _prep(prior_depth, "prior_depth")
+        B, _, h, w = prior.shape
+        zt = None
+        if z_trans is not None:
+            zt = _prep(z_trans, "z_trans").reshape(-1)
+            if zt.numel() != B:
+                # the reference broadcast only works for one lookup frame
+                raise RuntimeError("z_trans must have one value per sample (got %d for B=%d)" % (zt.numel(), B))
+        out = torch.empty(B, ndepth, h, w, device=prior.device, dtype=torch.float32)
+        _lib.call("md_schedule_depth_range", _p(prior), _p(zt), B, h, w, ndepth, float(scale_fac), _TYPES[type], _p(out),
+                  _stream())
+    return out
+
+
+# --------------------------------------------------------------------------- cost volume
+class _CostVolume(torch.autograd.Function):
+    """Grouped plane-sweep volume.  Returns a tensor of logical shape (B,D,G,h,w); with layout='bgd' its storage
+    is (B,G,D,h,w)-contiguous, i.e. `.permute(0,2,1,3,4)` (what reg3d does first) is contiguous."""
+
+    @staticmethod
+    def forward(ctx, ref, src, K, invK, pose, hyp, prior, ztrans, scale_fac, sched_type, G, D, layout):
+        ref, src = _prep(ref, "ref"), _prep(src, "src")
+        K, invK, pose = _prep(K, "K"), _prep(invK, "invK"), _prep(pose, "pose")
+        hyp, prior, ztrans = _prep(hyp, "depth_priors"), _prep(prior, "prior"), _prep(ztrans, "z_trans")
+        B, C, h, w = ref.shape
+        if layout == "bgd":
+            store = torch.empty(B, G, D, h, w, device=ref.device, dtype=torch.float32)
+            sb, sg, sd = store.stride(0), store.stride(1), store.stride(2)
+            out = store.permute(0, 2, 1, 3, 4)
+        else:
+            store = torch.empty(B, D, G, h, w, device=ref.device, dtype=torch.float32)
+            sb, sd, sg = store.stride(0), store.stride(1), store.stride(2)
+            out = store
+        _lib.call("md_costvol_fwd", _p(ref), _p(src), _p(K), _p(invK), _p(pose), _p(hyp), _p(prior), _p(ztrans),
+                  float(scale_fac), int(sched_type), B, C, G, h, w, D, _p(store), sb, sd, sg, _stream())
+        ctx.save_for_backward(ref, src, K, invK, pose, hyp if hyp is not None else torch.empty(0),
+                              prior if prior is not None else torch.empty(0),
+                              ztrans if ztrans is not None else torch.empty(0))
+        ctx.meta = (float(scale_fac), int(sched_type), G, D, layout, hyp is not None, prior is not None,
+                    ztrans is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        ref, src, K, invK, pose, hyp, prior, ztrans = ctx.saved_tensors
+        scale_fac, sched_type, G, D, layout, has_hyp, has_prior, has_z = ctx.meta
+        B, C, h, w = ref.shape
+        if layout == "bgd":
+            g = gout.permute(0, 2, 1, 3, 4).contiguous()  # no copy when the consumer produced (B,G,D,h,w)
+            sb, sg, sd = g.stride(0), g.stride(1), g.stride(2)
+        else:
+            g = gout.contiguous()
+            sb, sd, sg = g.stride(0), g.stride(1), g.stride(2)
+        if g.dtype != torch.float32:
+            g = g.float()
+        d_ref, d_src = torch.empty_like(ref), torch.empty_like(src)
+        _lib.call("md_costvol_bwd", _p(g), sb, sd, sg, _p(ref), _p(src), _p(K), _p(invK), _p(pose),
+                  _p(hyp if has_hyp else None), _p(prior if has_prior else None), _p(ztrans if has_z else None),
+                  scale_fac, sched_type, B, C, G, h, w, D, _p(d_ref), _p(d_src), _stream())
+        return (d_ref, d_src) + (None,) * 11
+
+
+def costvol_grouped(ref, src, K, invK, pose, G, depth_priors=None, prior=None, ndepth=None, scale_fac=0.3,
+                    z_trans=None, type="inverse", layout="bgd"):
+    """Plane-sweep volume with the group mean fused in.  Either `depth_priors` (B,D,h,w) or `prior` (B,1,h,w) +
+    schedule parameters (the schedule is then evaluated inside the kernel, same arithmetic as
+    schedule_depth_range).  pose: (B,4,4).  Returns logical (B,D,G,h,w)."""
+    if depth_priors is not None:
+        D = depth_priors.shape[1]
+        prior = None
+    else:
+        D = int(ndepth)
+    zt = None if (z_trans is None or depth_priors is not None) else z_trans.reshape(-1)
+    return _CostVolume.apply(ref, src, K, invK, pose.reshape(-1, 4, 4), depth_priors, prior, zt, scale_fac,
+                             _TYPES[type], int(G), D, layout)
+
+
+class _FuseVolumes(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, layout, *vols):
+        N = len(vols)
+        if layout == "bgd":
+            vs = [v.permute(0, 2, 1, 3, 4).contiguous() for v in vols]  # storage (B,G,D,h,w)
+            B, G, D, h, w = vs[0].shape
+            sb, sg, sd = vs[0].stride(0), vs[0].stride(1), vs[0].stride(2)
+        else:
+            vs = [v.contiguous() for v in vols]
+            B, D, G, h, w = vs[0].shape
+            sb, sd, sg = vs[0].stride(0), vs[0].stride(1), vs[0].stride(2)
+        store = torch.empty_like(vs[0])
+        weights = torch.empty(N, B, h, w, device=store.device, dtype=torch.float32)
+        arr = (ctypes.c_void_p * N)(*[v.data_ptr() for v in vs])
+        _lib.call("md_fuse_fwd", arr, N, B, D, G, h * w, sb, sd, sg, _p(store), _p(weights), _stream())
+        ctx.save_for_backward(*vs)
+        ctx.meta = (layout, N, B, D, G, h, w, sb, sd, sg)
+        ctx.mark_non_differentiable(weights)
+        out = store.permute(0, 2, 1, 3, 4) if layout == "bgd" else store
+        return out, weights
+
+    @staticmethod
+    def backward(ctx, gout, _gw):
+        vs = ctx.saved_tensors
+        layout, N, B, D, G, h, w, sb, sd, sg = ctx.meta
+        g = (gout.permute(0, 2, 1, 3, 4) if layout == "bgd" else gout).contiguous().float()
+        ds = [torch.empty_like(v) for v in vs]
+        arr = (ctypes.c_void_p * N)(*[v.data_ptr() for v in vs])
+        darr = (ctypes.c_void_p * N)(*[d.data_ptr() for d in ds])
+        _lib.call("md_fuse_bwd", _p(g), arr, N, B, D, G, h * w, sb, sd, sg, darr, _stream())
+        if layout == "bgd":
+            ds = [d.permute(0, 2, 1, 3, 4) for d in ds]
+        return (None,) + tuple(ds)
+
+
+def fuse_volumes(vols, layout="bgd", exact_single_frame=False):
+    """Confidence-weighted fusion over lookup frames (reference trainer.py:349-363) -> (cor_feats, weights|None).
+
+    With one lookup frame the reference's result equals its input to 1.6e-7 relative (w >= 1/G against the
+    1e-8 guard) and the gradient through w is O(1e-8); the kernel is then skipped unless exact_single_frame."""
+    if len(vols) == 1 and not exact_single_frame:
+        return vols[0], None
+    for v in vols:
+        if not v.is_cuda:
+            raise _lib.MovedepthHipError("cost volumes must be GPU tensors: the HIP path has no CPU fallback")
+    return _FuseVolumes.apply(layout, *[v.float() for v in vols])
+
+
+# --------------------------------------------------------------------------- photometric warp
+class _WarpBorder(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, img, depth, K, invK, T, want_pix, want_mask):
+        img, depth = _prep(img, "img"), _prep(depth, "depth")
+        K, invK, T = _prep(K, "K"), _prep(invK, "invK"), _prep(T, "T")
+        B, Ci, H, W = img.shape
+        if depth.numel() != B * H * W:
+            raise RuntimeError("depth has %d elements, expected B*H*W=%d" % (depth.numel(), B * H * W))
+        out = torch.empty_like(img)
+        pix = torch.empty(B, H, W, 2, device=img.device, dtype=torch.float32) if want_pix else None
+        mask = torch.empty(B, H, W, device=img.device, dtype=torch.uint8) if want_mask else None
+        _lib.call("md_warp_fwd", _p(img), _p(depth), _p(K), _p(invK), _p(T), B, Ci, H, W, _p(pix), _p(out), _p(mask),
+                  _stream())
+        ctx.save_for_backward(img, depth, K, invK, T)
+        if want_pix:
+            ctx.mark_non_differentiable(pix)
+        if want_mask:
+            ctx.mark_non_differentiable(mask)
+        return out, pix, mask
+
+    @staticmethod
+    def backward(ctx, gout, _gp, _gm):
+        img, depth, K, invK, T = ctx.saved_tensors
+        B, Ci, H, W = img.shape
+        g = gout.contiguous().float()
+        d_depth = torch.empty_like(depth)
+        d_T = torch.empty(B, 4, 4, device=img.device, dtype=torch.float32)
+        ws = _ws(_lib.load().md_warp_bwd_ws_bytes(B, H, W), img.device)
+        _lib.call("md_warp_bwd", _p(g), _p(img), _p(depth), _p(K), _p(invK), _p(T), B, Ci, H, W, _p(d_depth), _p(d_T),
+                  _p(ws), _stream())
+        return None, d_depth, None, None, d_T.reshape(T.shape), None, None
+
+
+def warp_border(img, depth, K, invK, T, want_pix=False, want_mask=False):
+    """backproject(depth, invK) -> project(K, T) -> grid_sample(img, border, align_corners=True), fused.
+    Gradients flow to `depth` and `T` (not to the image, as in the reference).  Returns (warped, pix, oob_mask)."""
+    return _WarpBorder.apply(img, depth, K, invK, T, bool(want_pix), bool(want_mask))
+
+
+class _DispToDepthUp(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, disp, H, W, min_depth, max_depth):
+        disp = _prep(disp, "disp")
+        B, _, h, w = disp.shape
+        depth = torch.empty(B, 1, H, W, device=disp.device, dtype=torch.float32)
+        _lib.call("md_disp_to_depth_up_fwd", _p(disp), B, h, w, H, W, float(min_depth), float(max_depth), _p(depth),
+                  _stream())
+        ctx.save_for_backward(disp)
+        ctx.meta = (H, W, float(min_depth), float(max_depth))
+        return depth
+
+    @staticmethod
+    def backward(ctx, g):
+        (disp,) = ctx.saved_tensors
+        H, W, mn, mx = ctx.meta
+        B, _, h, w = disp.shape
+        g = g.contiguous().float()
+        d = torch.empty_like(disp)
+        _lib.call("md_disp_to_depth_up_bwd", _p(g), _p(disp), B, h, w, H, W, mn, mx, _p(d), _stream())
+        return d, None, None, None, None
+
+
+def disp_to_depth_up(disp, H, W, min_depth, max_depth):
+    """F.interpolate(disp, [H,W], bilinear, align_corners=False) then disp_to_depth(...)[1] (trainer.py:512-514)."""
+    return _DispToDepthUp.apply(disp, int(H), int(W), min_depth, max_depth)
+
+
+# --------------------------------------------------------------------------- SSIM + L1
+def ssim_map(x, y):
+    """SSIM.forward (reference layers.py:663-677), forward only (the trainer uses reprojection_loss)."""
+    x, y = _prep(x, "x"), _prep(y, "y")
+    B, C, H, W = x.shape
+    out = torch.empty_like(x)
+    _lib.call("md_ssim", _p(x), _p(y), B, C, H, W, _p(out), _stream())
+    return out
+
+
+class _ReprojLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, target, ssim_w, no_ssim):
+        pred, target = _prep(pred, "pred"), _prep(target, "target")
+        B, C, H, W = pred.shape
+        out = torch.empty(B, 1, H, W, device=pred.device, dtype=torch.float32)
+        _lib.call("md_reproj_loss_fwd", _p(pred), _p(target), B, C, H, W, float(ssim_w), int(no_ssim), _p(out), _stream())
+        ctx.save_for_backward(pred, target)
+        ctx.meta = (float(ssim_w), int(no_ssim))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        pred, target = ctx.saved_tensors
+        ssim_w, no_ssim = ctx.meta
+        B, C, H, W = pred.shape
+        g = g.contiguous().float()
+        d = torch.empty_like(pred)
+        _lib.call("md_reproj_loss_bwd", _p(g), _p(pred), _p(target), B, C, H, W, ssim_w, no_ssim, _p(d), _stream())
+        return d, None, None, None
+
+
+def reprojection_loss(pred, target, ssim_w=0.85, no_ssim=False):
+    """compute_reprojection_loss (reference trainer.py:535-550) -> (B,1,H,W); gradient to `pred` only."""
+    return _ReprojLoss.apply(pred, target, ssim_w, no_ssim)
+
+
+# --------------------------------------------------------------------------- min / automask / masked mean
+class _MaskedMin(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, reproj, ident, noise, ext_mask, mvs_mode):
+        reproj = _prep(reproj, "reprojection_losses")
+        ident, noise, ext_mask = _prep(ident, "identity"), _prep(noise, "noise"), _prep(ext_mask, "mask")
+        B, N, H, W = reproj.shape
+        mn = torch.empty(B, 1, H, W, device=reproj.device, dtype=torch.float32)
+        mask = torch.empty_like(mn)
+        loss2 = torch.empty(2, device=reproj.device, dtype=torch.float32)
+        ws = _ws(_lib.load().md_masked_min_ws_bytes(B, H, W), reproj.device)
+        _lib.call("md_masked_min_fwd", _p(reproj), _p(ident), _p(noise), _p(ext_mask), B, N, H, W, int(mvs_mode), _p(mn),
+                  _p(mask), _p(loss2), _p(ws), _stream())
+        ctx.save_for_backward(reproj, mask, loss2)
+        ctx.mark_non_differentiable(mn, mask)
+        return loss2[0].clone(), mn, mask
+
+    @staticmethod
+    def backward(ctx, gloss, _g1, _g2):
+        reproj, mask, loss2 = ctx.saved_tensors
+        B, N, H, W = reproj.shape
+        gl = gloss.reshape(1).contiguous().float()
+        d = torch.empty_like(reproj)
+        _lib.call("md_masked_min_bwd", _p(gl), _p(reproj), _p(mask), _p(loss2), B, N, H, W, _p(d), _stream())
+        return d, None, None, None, None
+
+
+def masked_min_loss(reproj, ident=None, noise=None, ext_mask=None, mvs_mode=False):
+    """min over frames + automask + masked mean (reference trainer.py:687-709 / 630-662).
+    reproj, ident: (B,N,H,W).  Returns (loss scalar, min map (B,1,H,W), mask (B,1,H,W))."""
+    return _MaskedMin.apply(reproj, ident, noise, ext_mask, bool(mvs_mode))
+
+
+# --------------------------------------------------------------------------- smoothness
+class _Smooth(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, disp, img, normalize):
+        disp, img = _prep(disp, "disp"), _prep(img, "img")
+        B, Ci, h, w = img.shape
+        loss = torch.empty(1, device=disp.device, dtype=torch.float32)
+        ws = _ws(_lib.load().md_smooth_ws_bytes(B, h, w), disp.device)
+        _lib.call("md_smooth_fwd", _p(disp), _p(img), B, Ci, h, w, int(normalize), _p(loss), _p(ws), _stream())
+        ctx.save_for_backward(disp, img)
+        ctx.normalize = int(normalize)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        disp, img = ctx.saved_tensors
+        B, Ci, h, w = img.shape
+        gl = g.reshape(1).contiguous().float()
+        d = torch.empty_like(disp)
+        ws = _ws(_lib.load().md_smooth_ws_bytes(B, h, w), disp.device)
+        _lib.call("md_smooth_bwd", _p(gl), _p(disp), _p(img), B, Ci, h, w, ctx.normalize, _p(d), _p(ws), _stream())
+        return d, None, None
+
+
+def smooth_loss(disp, img, normalize=True):
+    """get_smooth_loss(disp / (mean_hw(disp) + 1e-7), img) (reference trainer.py:712-714, layers.py:630-643);
+    normalize=False is the bare get_smooth_loss.  Gradient to `disp` only."""
+    return _Smooth.apply(disp, img, bool(normalize))
+
+
+# --------------------------------------------------------------------------- post-volume regression
+class _SoftmaxEntropyLocalmax(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, min_inv, max_inv, radius, want_prob):
+        logits = _prep(logits, "logits")
+        min_inv, max_inv = _prep(min_inv, "min_depth_inverse"), _prep(max_inv, "max_depth_inverse")
+        B, D, h, w = logits.shape
+        prob = torch.empty_like(logits) if want_prob else None
+        ent = torch.empty(B, 1, h, w, device=logits.device, dtype=torch.float32)
+        depth = torch.empty(B, h, w, device=logits.device, dtype=torch.float32)
+        _lib.call("md_softmax_entropy_localmax_fwd", _p(logits), B, D, h, w, int(radius), _p(min_inv), _p(max_inv),
+                  _p(prob), _p(ent), _p(depth), _stream())
+        ctx.save_for_backward(logits, min_inv, max_inv)
+        ctx.radius = int(radius)
+        if want_prob:
+            ctx.mark_non_differentiable(prob)
+        return depth, ent, prob
+
+    @staticmethod
+    def backward(ctx, g_depth, g_ent, _gp):
+        logits, min_inv, max_inv = ctx.saved_tensors
+        B, D, h, w = logits.shape
+        gd = None if g_depth is None else g_depth.contiguous().float()
+        ge = None if g_ent is None else g_ent.contiguous().float()
+        d = torch.empty_like(logits)
+        _lib.call("md_softmax_entropy_localmax_bwd", _p(gd), _p(ge), _p(logits), B, D, h, w, ctx.radius, _p(min_inv),
+                  _p(max_inv), _p(d), _stream())
+        return d, None, None, None, None
+
+
+def softmax_entropy_localmax(logits, min_depth_inverse, max_depth_inverse, radius=1, want_prob=False):
+    """F.softmax(logits, 1) -> entropy(dim=1, keepdim) + localmax(...) in one pass (reference trainer.py:367-371).
+    Returns (depth (B,h,w), entropy (B,1,h,w), prob (B,D,h,w) or None [detached])."""
+    return _SoftmaxEntropyLocalmax.apply(logits, min_depth_inverse, max_depth_inverse, radius, want_prob)

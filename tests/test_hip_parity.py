@@ -1,0 +1,320 @@
+"""GPU parity: the HIP path (through the C ABI, via movedepth_amd.ops) against the CPU oracle on seeded inputs
+and against the golden fixtures generated from the reference.  Tolerance: north_star's 1e-4 relative fp32
+(norm-wise + max-abs bound, conftest.assert_close).  Run with `pytest -m gpu` on an MI355X."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import assert_close, load_golden, relerr
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    from movedepth_amd import _lib, ops
+
+    _lib.load()  # must exist: no fallback
+    return ops
+
+
+def dev(a, requires_grad=False):
+    t = torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32).cuda()
+    return t.requires_grad_(requires_grad)
+
+
+def host(t):
+    return t.detach().float().cpu().numpy()
+
+
+def kitti_K(h, w, B):
+    K = np.array([[0.58 * w, 0, 0.5 * w, 0], [0, 1.92 * h, 0.5 * h, 0], [0, 0, 1, 0], [0, 0, 0, 1]], np.float32)
+    invK = np.linalg.pinv(K).astype(np.float32)
+    return np.repeat(K[None], B, 0), np.repeat(invK[None], B, 0)
+
+
+def smooth_field(rng, shape, coarse=4, lo=0.0, hi=1.0):
+    *lead, H, W = shape
+    n = int(np.prod(lead)) if lead else 1
+    c = torch.from_numpy(rng.random((n, 1, max(2, H // coarse), max(2, W // coarse)), dtype=np.float32))
+    x = torch.nn.functional.interpolate(c, size=(H, W), mode="bilinear", align_corners=True)
+    return (lo + (hi - lo) * x).reshape(*shape).numpy().copy()
+
+
+def rand_pose(oracle, rng, B, rot=0.01, trans=0.05):
+    return oracle.transformation_from_parameters(rng.standard_normal((B, 3)).astype(np.float32) * rot,
+                                                 rng.standard_normal((B, 3)).astype(np.float32) * trans)
+
+
+# ------------------------------------------------------------------ schedule
+@pytest.mark.parametrize("ty", ["inverse", "linear", "log"])
+def test_schedule_golden(ops, ty):
+    g = load_golden("schedule")
+    D, f = int(g["ndepth"]), float(g["scale_fac"])
+    assert_close(host(ops.schedule_depth_range(dev(g["prior"]), D, f, None, ty)), g["v2_" + ty], rtol=1e-5)
+    assert_close(host(ops.schedule_depth_range(dev(g["prior"]), D, f, dev(g["z_trans"]), ty)), g["zv2_" + ty], rtol=1e-5)
+
+
+# ------------------------------------------------------------------ cost volume
+COSTVOL_CASES = ["small", "white", "oob", "zv2", "c64g8"]
+
+
+@pytest.mark.parametrize("layout", ["bgd", "bdg"])
+@pytest.mark.parametrize("tag", COSTVOL_CASES)
+def test_costvol_golden(ops, tag, layout):
+    g = load_golden("costvol_" + tag)
+    G = int(g["G"])
+    ref, src = dev(g["ref"], True), dev(g["src0"], True)
+    vol = ops.costvol_grouped(ref, src, dev(g["K"]), dev(g["invK"]), dev(g["pose"][:, 0]), G,
+                              depth_priors=dev(g["hyp"]), layout=layout)
+    assert vol.shape == g["grouped0"].shape
+    assert_close(host(vol), g["grouped0"], what="grouped volume")
+    cor, w = ops.fuse_volumes([vol], layout=layout, exact_single_frame=True)
+    assert_close(host(cor), g["cor_feats"], what="cor_feats")
+    assert_close(host(w[0]), g["cor_weight0"], rtol=1e-5)
+    (cor * dev(g["grad_out"])).sum().backward()
+    assert_close(host(ref.grad), g["d_ref"], what="d_ref")
+    assert_close(host(src.grad), g["d_src0"], what="d_src")
+    # single-frame fast path (fusion skipped): identical to 1e-6
+    cor_fast, _ = ops.fuse_volumes([vol.detach()], layout=layout)
+    assert relerr(host(cor_fast), g["cor_feats"]) < 1e-4
+
+
+def test_costvol_ungrouped_golden(ops):
+    """G == C reproduces the reference's (B,D,C,h,w) generate_costvol output."""
+    g = load_golden("costvol_small")
+    C = g["ref"].shape[1]
+    vol = ops.costvol_grouped(dev(g["ref"]), dev(g["src0"]), dev(g["K"]), dev(g["invK"]), dev(g["pose"][:, 0]), C,
+                              depth_priors=dev(g["hyp"]), layout="bdg")
+    assert_close(host(vol), g["cost_vol_full0"])
+
+
+def test_costvol_twoframe_golden(ops):
+    g = load_golden("costvol_twoframe")
+    G = int(g["G"])
+    ref = dev(g["ref"], True)
+    srcs = [dev(g["src%d" % f], True) for f in range(2)]
+    vols = [ops.costvol_grouped(ref, srcs[f], dev(g["K"]), dev(g["invK"]), dev(g["pose"][:, f]), G,
+                                depth_priors=dev(g["hyp"])) for f in range(2)]
+    cor, w = ops.fuse_volumes(vols)
+    assert_close(host(cor), g["cor_feats"], what="two-frame cor_feats")
+    for f in range(2):
+        assert_close(host(w[f]), g["cor_weight%d" % f], rtol=1e-5)
+    (cor * dev(g["grad_out"])).sum().backward()
+    assert_close(host(ref.grad), g["d_ref"], what="d_ref")
+    for f in range(2):
+        assert_close(host(srcs[f].grad), g["d_src%d" % f], what="d_src%d" % f)
+
+
+@pytest.mark.parametrize("case", [
+    dict(B=2, C=32, G=16, h=24, w=40, D=12, rot=0.01, trans=0.05),            # ragged tiles (w, h not tile multiples)
+    dict(B=1, C=32, G=16, h=48, w=160, D=32, rot=0.01, trans=0.05),           # BASELINE feature size, D slice
+    dict(B=2, C=32, G=16, h=16, w=64, D=8, rot=0.3, trans=2.0),               # wild pose: window misses, zero padding
+    dict(B=1, C=32, G=32, h=12, w=20, D=5, rot=0.02, trans=0.1),              # ungrouped
+    dict(B=1, C=64, G=16, h=12, w=20, D=5, rot=0.02, trans=0.1),              # 4 channels per group
+])
+@pytest.mark.parametrize("fused", [False, True])
+def test_costvol_vs_oracle(ops, oracle_lib, case, fused):
+    rng = np.random.default_rng(7)
+    B, C, G, h, w, D = (case[k] for k in "BCGhwD")
+    ref = smooth_field(rng, (B, C, h, w), 3, -1, 1)
+    src = smooth_field(rng, (B, C, h, w), 3, -1, 1)
+    K, invK = kitti_K(h, w, B)
+    prior = (2 + 20 * rng.random((B, 1, h, w))).astype(np.float32)
+    pose = rand_pose(oracle_lib, rng, B, case["rot"], case["trans"])
+    z = 30.0 * pose[:, 2, 3]
+    hyp = oracle_lib.schedule_depth_range(prior, D, 0.3, z, "inverse")
+    gout = rng.standard_normal((B, D, G, h, w)).astype(np.float32)
+    exp = oracle_lib.costvol_grouped(ref, src, K, invK, hyp, pose, G)
+    exp_dref, exp_dsrc = oracle_lib.costvol_grouped_bwd(gout, ref, src, K, invK, hyp, pose)
+    r, s = dev(ref, True), dev(src, True)
+    if fused:  # schedule evaluated inside the kernel
+        vol = ops.costvol_grouped(r, s, dev(K), dev(invK), dev(pose), G, prior=dev(prior), ndepth=D, scale_fac=0.3,
+                                  z_trans=dev(z), type="inverse")
+    else:
+        vol = ops.costvol_grouped(r, s, dev(K), dev(invK), dev(pose), G, depth_priors=dev(hyp))
+    assert_close(host(vol), exp, what="volume")
+    (vol * dev(gout)).sum().backward()
+    assert_close(host(r.grad), exp_dref, what="d_ref")
+    assert_close(host(s.grad), exp_dsrc, what="d_src")
+
+
+def test_costvol_full_size_properties(ops):
+    """BASELINE config 2 size (B=6, 48x160, D=96, C=32, G=16): size-independent properties instead of the oracle.
+    (1) identity pose => volume == group-mean(ref*src) for every hypothesis (KAT1);
+    (2) linearity in ref and in src;  (3) <vol, g> == <ref, d_ref> == <src, d_src> (adjoint identity)."""
+    torch.manual_seed(0)
+    B, C, G, h, w, D = 6, 32, 16, 48, 160, 96
+    Knp, invKnp = kitti_K(h, w, B)
+    K, invK = dev(Knp), dev(invKnp)
+    ref = torch.randn(B, C, h, w, device="cuda")
+    src = torch.randn(B, C, h, w, device="cuda")
+    prior = 2 + 20 * torch.rand(B, 1, h, w, device="cuda")
+    eye = torch.eye(4, device="cuda").repeat(B, 1, 1)
+    kw = dict(prior=prior, ndepth=D, scale_fac=0.3, type="inverse")
+    vol = ops.costvol_grouped(ref, src, K, invK, eye, G, **kw)
+    exp = (ref * src).reshape(B, 2, G, h, w).mean(1)[:, None].expand(B, D, G, h, w)
+    assert float((vol - exp).abs().max()) < 5e-4  # coordinate round trip is not bit exact (SURVEY KAT1)
+    pose = eye.clone()
+    pose[:, 0, 3] = 0.05
+    pose[:, 2, 3] = 0.03
+    ref2, src2 = torch.randn_like(ref), torch.randn_like(src)
+    v1 = ops.costvol_grouped(ref, src, K, invK, pose, G, **kw)
+    v2 = ops.costvol_grouped(ref2, src, K, invK, pose, G, **kw)
+    v12 = ops.costvol_grouped(ref + 2 * ref2, src, K, invK, pose, G, **kw)
+    assert relerr(host(v12), host(v1 + 2 * v2)) < 1e-5
+    v3 = ops.costvol_grouped(ref, src2, K, invK, pose, G, **kw)
+    v13 = ops.costvol_grouped(ref, src - 3 * src2, K, invK, pose, G, **kw)
+    assert relerr(host(v13), host(v1 - 3 * v3)) < 1e-5
+    r, s = ref.clone().requires_grad_(True), src.clone().requires_grad_(True)
+    v = ops.costvol_grouped(r, s, K, invK, pose, G, **kw)
+    g = torch.randn_like(v)
+    (v * g).sum().backward()
+    lhs = float((v.double() * g.double()).sum())
+    assert abs(float((r.double() * r.grad.double()).sum()) - lhs) < 1e-4 * abs(lhs)
+    assert abs(float((s.double() * s.grad.double()).sum()) - lhs) < 1e-4 * abs(lhs)
+
+
+# ------------------------------------------------------------------ warp
+@pytest.mark.parametrize("tag", ["small", "border"])
+def test_warp_golden(ops, tag):
+    g = load_golden("warp_" + tag)
+    depth, T = dev(g["depth"], True), dev(g["T"], True)
+    out, pix, mask = ops.warp_border(dev(g["img"]), depth, dev(g["K"]), dev(g["invK"]), T, want_pix=True, want_mask=True)
+    assert_close(host(pix), g["pix_coords"], rtol=1e-5)
+    assert_close(host(out), g["warped"])
+    assert (host(mask).astype(bool) != g["mvs_mask"]).mean() < 2e-3
+    (out * dev(g["grad_out"])).sum().backward()
+    assert_close(host(depth.grad), g["d_depth"], rtol=2e-4, atol_scale=5e-3, what="d_depth")
+    assert_close(host(T.grad), g["d_T"], rtol=2e-4, what="d_T")
+
+
+def test_warp_vs_oracle_fullres(ops, oracle_lib):
+    rng = np.random.default_rng(3)
+    B, H, W = 2, 192, 640
+    img = smooth_field(rng, (B, 3, H, W), 8)
+    depth = (2 + 20 * smooth_field(rng, (B, 1, H, W), 16)).astype(np.float32)
+    K, invK = kitti_K(H, W, B)
+    T = rand_pose(oracle_lib, rng, B, 0.01, 0.1)
+    gout = rng.standard_normal((B, 3, H, W)).astype(np.float32)
+    exp, exp_pix = oracle_lib.warp(img, depth, K, invK, T)
+    exp_dd, exp_dT = oracle_lib.warp_bwd(gout, img, depth, K, invK, T)
+    d, t = dev(depth, True), dev(T, True)
+    out, pix, _ = ops.warp_border(dev(img), d, dev(K), dev(invK), t, want_pix=True)
+    assert_close(host(pix), exp_pix, rtol=1e-5)
+    assert_close(host(out), exp)
+    (out * dev(gout)).sum().backward()
+    assert_close(host(d.grad).reshape(exp_dd.shape), exp_dd, rtol=2e-4, atol_scale=5e-3)
+    assert_close(host(t.grad), exp_dT, rtol=2e-4)
+
+
+@pytest.mark.parametrize("hw", [(4, 8), (8, 16), (16, 32), (32, 64)])
+def test_disp_to_depth_up(ops, oracle_lib, hw):
+    rng = np.random.default_rng(5)
+    B, H, W = 2, 32, 64
+    h, w = hw
+    disp = (0.01 + 0.5 * rng.random((B, 1, h, w))).astype(np.float32)
+    up = oracle_lib.resize_bilinear(disp, H, W)
+    _, exp = oracle_lib.disp_to_depth(up, 0.1, 100.0)
+    d = dev(disp, True)
+    depth = ops.disp_to_depth_up(d, H, W, 0.1, 100.0)
+    assert_close(host(depth), exp, rtol=1e-5)
+    g = rng.standard_normal((B, 1, H, W)).astype(np.float32)
+    (depth * dev(g)).sum().backward()
+    sd = 1.0 / exp
+    g_up = -g * (1 / 0.1 - 1 / 100.0) * exp * exp
+    exp_d = oracle_lib.resize_bilinear_bwd(g_up.astype(np.float32), h, w)
+    assert_close(host(d.grad), exp_d, rtol=2e-5)
+
+
+# ------------------------------------------------------------------ SSIM / reprojection loss
+def test_ssim_golden(ops):
+    g = load_golden("ssim")
+    assert_close(host(ops.ssim_map(dev(g["pred"]), dev(g["target"]))), g["ssim"])
+    pred = dev(g["pred"], True)
+    rl = ops.reprojection_loss(pred, dev(g["target"]))
+    assert_close(host(rl), g["reproj"])
+    (rl * dev(g["grad_out"])).sum().backward()
+    assert_close(host(pred.grad), g["d_pred"], rtol=2e-4)
+    pred.grad = None
+    rl0 = ops.reprojection_loss(pred, dev(g["target"]), ssim_w=0.0)
+    assert_close(host(rl0), g["reproj_l1only"], rtol=1e-6)
+    (rl0 * dev(g["grad_out"])).sum().backward()
+    assert_close(host(pred.grad), g["d_pred_l1only"], rtol=1e-6)
+    assert float(ops.ssim_map(dev(g["kat_x"]), dev(g["kat_x"])).abs().max()) < 1e-6  # KAT5
+    z, o = torch.zeros(1, 3, 8, 8, device="cuda"), torch.ones(1, 3, 8, 8, device="cuda")
+    assert abs(float(ops.ssim_map(z, o).mean()) - 0.49995) < 1e-5
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 192, 640), (1, 3, 37, 71), (2, 3, 3, 3)])
+def test_reproj_loss_vs_oracle(ops, oracle_lib, shape):
+    rng = np.random.default_rng(11)
+    B, C, H, W = shape
+    x = smooth_field(rng, shape, 2) if H > 8 else rng.random(shape, dtype=np.float32)
+    y = smooth_field(rng, shape, 2) if H > 8 else rng.random(shape, dtype=np.float32)
+    g = rng.standard_normal((B, 1, H, W)).astype(np.float32)
+    p = dev(x, True)
+    out = ops.reprojection_loss(p, dev(y))
+    assert_close(host(out), oracle_lib.reproj_loss(x, y))
+    (out * dev(g)).sum().backward()
+    assert_close(host(p.grad), oracle_lib.reproj_loss_bwd(g, x, y), rtol=2e-4)
+    assert_close(host(ops.ssim_map(dev(x), dev(y))), oracle_lib.ssim(x, y))
+
+
+# ------------------------------------------------------------------ reductions
+@pytest.mark.parametrize("mode", ["automask", "plain", "mvs", "ext"])
+def test_masked_min_vs_oracle(ops, oracle_lib, mode):
+    rng = np.random.default_rng(13)
+    B, N, H, W = 2, 2, 48, 80
+    rp = rng.random((B, N, H, W), dtype=np.float32)
+    idn = rng.random((B, N, H, W), dtype=np.float32)
+    noise = (rng.standard_normal((B, 1, H, W)) * 1e-5).astype(np.float32)
+    ext = (rng.random((B, 1, H, W)) > 0.3).astype(np.float32)
+    kw = dict(automask=dict(ident=idn, noise=noise), plain={}, mvs=dict(ident=idn, noise=noise, mvs_mode=True),
+              ext=dict(ext_mask=ext))[mode]
+    emn, emask, eloss = oracle_lib.masked_min(rp, **kw)
+    r = dev(rp, True)
+    loss, mn, mask = ops.masked_min_loss(r, **{k: (dev(v) if isinstance(v, np.ndarray) else v) for k, v in kw.items()})
+    assert abs(float(loss) - eloss) < 1e-5 * abs(eloss)
+    assert np.array_equal(host(mask), emask)
+    assert np.array_equal(host(mn), emn)
+    (loss * 1.7).backward()
+    assert_close(host(r.grad), oracle_lib.masked_min_bwd(1.7, rp, emask), rtol=1e-5)
+
+
+@pytest.mark.parametrize("normalize", [True, False])
+def test_smooth_vs_oracle_and_golden(ops, oracle_lib, normalize):
+    g = load_golden("smooth")
+    d = dev(g["disp"], True)
+    loss = ops.smooth_loss(d, dev(g["img"]), normalize)
+    exp = float(g["smooth_norm"] if normalize else g["smooth_raw"])
+    assert abs(float(loss) - exp) < 1e-5 * exp
+    if normalize:
+        loss.backward()
+        assert_close(host(d.grad), g["d_disp"])
+    rng = np.random.default_rng(17)
+    B, h, w = 3, 96, 320
+    disp = (0.01 + rng.random((B, 1, h, w))).astype(np.float32)
+    img = smooth_field(rng, (B, 3, h, w), 4)
+    dd = dev(disp, True)
+    l2 = ops.smooth_loss(dd, dev(img), normalize)
+    e2 = oracle_lib.smooth_loss(disp, img, normalize)
+    assert abs(float(l2) - e2) < 2e-5 * e2
+    (l2 * 2.0).backward()
+    assert_close(host(dd.grad), oracle_lib.smooth_loss_bwd(2.0, disp, img, normalize))
+
+
+# ------------------------------------------------------------------ post-volume
+def test_postvol_golden(ops):
+    g = load_golden("postvol")
+    hyp = g["hyp"]
+    logits = dev(g["logits"], True)
+    depth, ent, prob = ops.softmax_entropy_localmax(logits, dev(1 / hyp[:, -1]), dev(1 / hyp[:, 0]), 1, want_prob=True)
+    assert_close(host(depth), g["depth_r1"], rtol=1e-5)
+    assert_close(host(ent), g["entropy"], rtol=1e-5)
+    assert_close(host(prob), torch.softmax(torch.from_numpy(g["logits"]), 1).numpy(), rtol=1e-5)
+    ((depth * dev(g["grad_depth"])).sum() + (ent * dev(g["grad_entropy"])).sum()).backward()
+    assert_close(host(logits.grad), g["d_logits"], rtol=2e-4)
+    d2, _, _ = ops.softmax_entropy_localmax(dev(g["logits"]), dev(1 / hyp[:, -1]), dev(1 / hyp[:, 0]), 2)
+    assert_close(host(d2), g["depth_r2"], rtol=1e-5)
