@@ -10,54 +10,60 @@
 //               and one slice of the D hypotheses;  grid = (tiles, G/GS, B*DSPLIT).
 //   thread    = one reference pixel; it walks its D slice, so the hypotheses of a pixel ("per-pixel
 //               depth hypotheses") never leave registers and each wave store is a 128/256-byte row piece.
+//               With the fused schedule the per-bin interval positions k/(D-1) sit in a small LDS table.
 //   LDS       = the source-feature window the tile's epipolar segments can reach, staged ONCE per
 //               workgroup channels-last ([pixel][CPW] as 16-byte quads, XOR-swizzled so a wave's
 //               ds_read_b128 taps are bank-conflict free), zero-filled outside the image: that is
 //               grid_sample's 'zeros' padding for free.  Taps are 4 x CPW/4 ds_read_b128 per hypothesis
 //               instead of 4 x CPW scattered global loads.  The window origin comes from the tile's
 //               bounding box of tap positions at the first and last hypothesis of the slice; taps that
-//               still fall outside (wild poses) take a slow, correct global-memory path.
-//   backward  = same walk; d_ref accumulates in registers, d_src is scattered with ds_add_f32 into a
-//               planar LDS window and flushed once per workgroup with global float atomics.
+//               still fall outside (wild poses) take a slow, correct global-memory path (out of line).
+//   backward  = same walk; d_ref accumulates in registers.  d_src contributions accumulate in registers
+//               while consecutive hypotheses land in the same source cell (an epipolar segment spans
+//               ~1-2 px over the depth range) and are scattered with ds_add_f32 into a planar LDS window
+//               only when the cell changes -- LDS float atomics are ~50x slower than integer ones on gfx950
+//               (measured: 3.1 ms vs 0.22 ms for the same scatter), so they must be rare -- then flushed
+//               once per workgroup with global float atomics.
 #include <limits.h>
 
 #include "md_common.hpp"
 
 namespace {
 
-struct CostvolArgs {
-    const float *ref, *src, *K, *invK, *pose, *hyp, *prior, *ztrans;
+// true: follow Project3D's operation order step by step (P @ (depth * ray), /(w-1), -0.5, *2, then grid_sample's
+// un-normalise); false: the algebraically identical 3-FMA form.  The two differ by a few ulp of the pixel coordinate
+// (<= ~2e-5 px at 160 px), the same order as the reference's own CPU-vs-CPU coordinate noise (SURVEY KAT1: 5e-5).
+#ifndef MD_COSTVOL_REFERENCE_OP_ORDER
+#define MD_COSTVOL_REFERENCE_OP_ORDER 0
+#endif
+constexpr bool kReferenceOpOrder = MD_COSTVOL_REFERENCE_OP_ORDER != 0;
+
+constexpr int ITV_MAX = 256;  // hypotheses per D slice served from the LDS interval table
+
+struct CvDims {
     float scale_fac;
     int sched_type;
     int B, C, G, h, w, D;
     int dsplit, dper;
     int tiles_x;
-    // forward: out; backward: gout (same addressing)
-    float *out;
-    const float *gout;
+    int dbg;  // tuning only (MD_COSTVOL_DEBUG bitmask); 0 in production
     long long sb, sd, sg;
-    float *d_ref, *d_src;
 };
 
-template <int TW>
+// Window = tile + epipolar reach.  The reach shrinks when a workgroup carries 32 channels (128 B per pixel)
+// so that two workgroups still fit a CU's 160 KB of LDS.
+template <int TW, int CPW>
 struct Tile {
     static constexpr int TH = 256 / TW;
-    static constexpr int WW = TW + 16;  // window: tile + 16 columns / 8 rows of epipolar reach
-    static constexpr int WH = TH + 8;
+    static constexpr int WW = TW + (CPW >= 32 ? 8 : 16);
+    static constexpr int WH = TH + (CPW >= 32 ? 4 : 8);
+    static constexpr int WP = WW * WH;
 };
 
-// swizzled quad index inside a pixel's QPP quads (see header comment)
-template <int QPP>
-__device__ __forceinline__ int swz(int wx, int q) {
-    if (QPP == 1) return 0;
-    return q ^ ((wx / (16 / QPP)) & (QPP - 1));
-}
+template <int CPW>
+using vecf = float __attribute__((ext_vector_type(CPW)));
+using v2f = float __attribute__((ext_vector_type(2)));
 
-// Hypothesis for (pixel, k): from the hyp tensor or the fused schedule.
-__device__ __forceinline__ float load_hyp(const CostvolArgs &a, int b, int k, int p, float prior_c, float one_pf) {
-    if (a.hyp) return a.hyp[((size_t)b * a.D + k) * (size_t)(a.h * a.w) + p];
-    return md_hypothesis(prior_c, one_pf, k, a.D, a.sched_type);
-}
 
 // channel held in LDS slot k of this workgroup: slot k = j*N + i  ->  channel i*G + gbase + j
 template <int N>
@@ -65,253 +71,408 @@ __device__ __forceinline__ int slot_channel(int k, int G, int gbase) {
     return (k % N) * G + gbase + k / N;
 }
 
-// Tile set-up shared by forward and backward: camera constants, the thread's pixel/ray, the window origin,
-// and the staged source window.
-template <int GS, int N, int TW>
-struct Setup {
-    static constexpr int CPW = GS * N;
-    static constexpr int QPP = CPW / 4;
-    using T = Tile<TW>;
-
-    CamMats cam;
-    int b, ds, gbase, x, y, p;
-    bool valid;
-    float r0, r1, r2, prior_c, one_pf;
-    int d0, d1, ox, oy;
-
-    __device__ __forceinline__ void init(const CostvolArgs &a, float4 *win, int *bb) {
-        const int tid = threadIdx.x;
-        b = blockIdx.z / a.dsplit;
-        ds = blockIdx.z % a.dsplit;
-        gbase = blockIdx.y * GS;
-        const int tx0 = (blockIdx.x % a.tiles_x) * TW, ty0 = (blockIdx.x / a.tiles_x) * T::TH;
-        x = tx0 + tid % TW;
-        y = ty0 + tid / TW;
-        valid = x < a.w && y < a.h;
-        p = y * a.w + x;
-        d0 = ds * a.dper;
-        d1 = min(a.D, d0 + a.dper);
-        cam = md_load_cam(a.K + b * 16, a.invK + b * 16, a.pose + b * 16);
-        md_ray(cam, (float)x, (float)y, r0, r1, r2);
-        prior_c = 1.f;
-        one_pf = 1.f;
-        if (!a.hyp) {
-            one_pf = 1.f + (a.ztrans ? a.scale_fac * a.ztrans[b] : a.scale_fac);
-            if (valid) prior_c = a.prior[(size_t)b * a.h * a.w + p];
-        }
-        // bounding box of the north-west taps at both ends of the hypothesis slice (u(d), v(d) are
-        // monotone in d between them unless c_z changes sign; stragglers take the global path)
-        int mnx = INT_MAX, mny = INT_MAX, mxx = INT_MIN, mxy = INT_MIN;
-        if (valid && d1 > d0) {
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                int k = e ? d1 - 1 : d0;
-                Proj pr = md_project(cam, r0, r1, r2, load_hyp(a, b, k, p, prior_c, one_pf), a.w, a.h);
-                Tap t = md_make_tap(pr.ix, pr.iy, a.w, a.h);
-                if (t.x0 >= -1 && t.x0 < a.w && t.y0 >= -1 && t.y0 < a.h) {
-                    mnx = min(mnx, t.x0); mxx = max(mxx, t.x0 + 1);
-                    mny = min(mny, t.y0); mxy = max(mxy, t.y0 + 1);
-                }
-            }
-        }
-        mnx = md_wave_min(mnx); mny = md_wave_min(mny); mxx = md_wave_max(mxx); mxy = md_wave_max(mxy);
-        const int wave = tid >> 6;
-        if ((tid & 63) == 0) { bb[wave * 4] = mnx; bb[wave * 4 + 1] = mny; bb[wave * 4 + 2] = mxx; bb[wave * 4 + 3] = mxy; }
-        __syncthreads();
-#pragma unroll
-        for (int wv = 0; wv < 4; ++wv) {
-            mnx = min(mnx, bb[wv * 4]); mny = min(mny, bb[wv * 4 + 1]);
-            mxx = max(mxx, bb[wv * 4 + 2]); mxy = max(mxy, bb[wv * 4 + 3]);
-        }
-        if (mnx > mxx) { mnx = tx0; mxx = tx0; mny = ty0; mxy = ty0; }  // nothing lands in the image
-        int spanx = mxx - mnx + 1, spany = mxy - mny + 1;
-        ox = spanx <= T::WW ? mnx : mnx + (spanx - T::WW) / 2;
-        oy = spany <= T::WH ? mny : mny + (spany - T::WH) / 2;
-        // stage the window: consecutive threads -> consecutive columns (coalesced per channel plane)
-        const size_t hw = (size_t)a.h * a.w;
-        const float *srcb = a.src + (size_t)b * a.C * hw;
-        for (int idx = tid; idx < T::WW * T::WH * QPP; idx += 256) {
-            int wx = idx % T::WW, rest = idx / T::WW;
-            int wy = rest % T::WH, q = rest / T::WH;
-            int sx = ox + wx, sy = oy + wy;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (sx >= 0 && sx < a.w && sy >= 0 && sy < a.h) {
-                size_t o = (size_t)sy * a.w + sx;
-                v.x = srcb[(size_t)slot_channel<N>(q * 4 + 0, a.G, gbase) * hw + o];
-                v.y = srcb[(size_t)slot_channel<N>(q * 4 + 1, a.G, gbase) * hw + o];
-                v.z = srcb[(size_t)slot_channel<N>(q * 4 + 2, a.G, gbase) * hw + o];
-                v.w = srcb[(size_t)slot_channel<N>(q * 4 + 3, a.G, gbase) * hw + o];
-            }
-            win[(wy * T::WW + wx) * QPP + swz<QPP>(wx, q)] = v;
-        }
-        __syncthreads();
+// In-register 4x4 transpose across the four lanes of a quad (two DPP quad_perm butterfly stages, no LDS):
+// before, lane j holds v[r] = M[j][r]; after, lane j holds v[r] = M[r][j].
+template <int CTRL>
+__device__ __forceinline__ float quad_perm(float x) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ void quad_transpose(float (&v)[4]) {
+    const int lane = threadIdx.x;
+    {   // exchange with lane^1 (quad_perm [1,0,3,2]), registers r <-> r^1
+        const float s0 = quad_perm<0xB1>(v[0]), s1 = quad_perm<0xB1>(v[1]), s2 = quad_perm<0xB1>(v[2]), s3 = quad_perm<0xB1>(v[3]);
+        const bool odd = lane & 1;
+        const float n0 = odd ? s1 : v[0], n1 = odd ? v[1] : s0, n2 = odd ? s3 : v[2], n3 = odd ? v[3] : s2;
+        v[0] = n0; v[1] = n1; v[2] = n2; v[3] = n3;
     }
-
-    // Bilinear samples S[k] of the CPW staged channels at tap t ('zeros' padding).
-    __device__ __forceinline__ void sample(const CostvolArgs &a, const float4 *win, const Tap &t, float *S,
-                                           bool &in_win) const {
-        const float wx0 = 1.f - t.wx1, wy0 = 1.f - t.wy1;
-        const float w00 = wy0 * wx0, w01 = wy0 * t.wx1, w10 = t.wy1 * wx0, w11 = t.wy1 * t.wx1;
-        const int lx = t.x0 - ox, ly = t.y0 - oy;
-        const bool dead = t.x0 < -1 || t.x0 >= a.w || t.y0 < -1 || t.y0 >= a.h;
-        in_win = lx >= 0 && lx + 1 < T::WW && ly >= 0 && ly + 1 < T::WH;
-        if (dead) {
-#pragma unroll
-            for (int k = 0; k < CPW; ++k) S[k] = 0.f;
-            in_win = false;
-        } else if (in_win) {
-            const int base0 = (ly * T::WW + lx) * QPP, base1 = base0 + T::WW * QPP;
-#pragma unroll
-            for (int q = 0; q < QPP; ++q) {
-                float4 a00 = win[base0 + swz<QPP>(lx, q)], a01 = win[base0 + QPP + swz<QPP>(lx + 1, q)];
-                float4 a10 = win[base1 + swz<QPP>(lx, q)], a11 = win[base1 + QPP + swz<QPP>(lx + 1, q)];
-                S[q * 4 + 0] = a00.x * w00 + a01.x * w01 + a10.x * w10 + a11.x * w11;
-                S[q * 4 + 1] = a00.y * w00 + a01.y * w01 + a10.y * w10 + a11.y * w11;
-                S[q * 4 + 2] = a00.z * w00 + a01.z * w01 + a10.z * w10 + a11.z * w11;
-                S[q * 4 + 3] = a00.w * w00 + a01.w * w01 + a10.w * w10 + a11.w * w11;
-            }
-        } else {
-            // slow path: tap inside the image but outside the staged window
-            const size_t hw = (size_t)a.h * a.w;
-            const float *srcb = a.src + (size_t)b * a.C * hw;
-            const int x1 = t.x0 + 1, y1 = t.y0 + 1;
-            const bool vx0 = t.x0 >= 0, vx1 = x1 < a.w, vy0 = t.y0 >= 0, vy1 = y1 < a.h;
-#pragma unroll
-            for (int k = 0; k < CPW; ++k) {
-                const float *pl = srcb + (size_t)slot_channel<N>(k, a.G, gbase) * hw;
-                float s = 0.f;
-                if (vx0 && vy0) s += pl[t.y0 * a.w + t.x0] * w00;
-                if (vx1 && vy0) s += pl[t.y0 * a.w + x1] * w01;
-                if (vx0 && vy1) s += pl[y1 * a.w + t.x0] * w10;
-                if (vx1 && vy1) s += pl[y1 * a.w + x1] * w11;
-                S[k] = s;
-            }
-        }
-    }
-};
-
-template <int GS, int N, int TW>
-__global__ __launch_bounds__(256) void costvol_fwd_kernel(CostvolArgs a) {
-    using SU = Setup<GS, N, TW>;
-    using T = Tile<TW>;
-    constexpr int CPW = SU::CPW, QPP = SU::QPP;
-    __shared__ float4 win[T::WW * T::WH * QPP];
-    __shared__ int bb[16];
-    SU s;
-    s.init(a, win, bb);
-    if (!s.valid) return;
-
-    const size_t hw = (size_t)a.h * a.w;
-    float rf[CPW];
-#pragma unroll
-    for (int k = 0; k < CPW; ++k) rf[k] = a.ref[((size_t)s.b * a.C + slot_channel<N>(k, a.G, s.gbase)) * hw + s.p];
-
-    float *outp = a.out + (size_t)s.b * a.sb + (size_t)s.gbase * a.sg + s.p;
-    float dnext = load_hyp(a, s.b, s.d0, s.p, s.prior_c, s.one_pf);
-    for (int d = s.d0; d < s.d1; ++d) {
-        const float dep = dnext;
-        if (d + 1 < s.d1) dnext = load_hyp(a, s.b, d + 1, s.p, s.prior_c, s.one_pf);
-        Proj pr = md_project(s.cam, s.r0, s.r1, s.r2, dep, a.w, a.h);
-        Tap t = md_make_tap(pr.ix, pr.iy, a.w, a.h);
-        float S[CPW];
-        bool in_win;
-        s.sample(a, win, t, S, in_win);
-#pragma unroll
-        for (int j = 0; j < GS; ++j) {
-            float acc = 0.f;
-#pragma unroll
-            for (int i = 0; i < N; ++i) acc += S[j * N + i] * rf[j * N + i];
-            outp[(size_t)d * a.sd + (size_t)j * a.sg] = acc / (float)N;
-        }
+    {   // exchange with lane^2 (quad_perm [2,3,0,1]), registers r <-> r^2
+        const float s0 = quad_perm<0x4E>(v[0]), s1 = quad_perm<0x4E>(v[1]), s2 = quad_perm<0x4E>(v[2]), s3 = quad_perm<0x4E>(v[3]);
+        const bool hi = lane & 2;
+        const float n0 = hi ? s2 : v[0], n1 = hi ? s3 : v[1], n2 = hi ? v[2] : s0, n3 = hi ? v[3] : s1;
+        v[0] = n0; v[1] = n1; v[2] = n2; v[3] = n3;
     }
 }
 
-template <int GS, int N, int TW>
-__global__ __launch_bounds__(256) void costvol_bwd_kernel(CostvolArgs a) {
-    using SU = Setup<GS, N, TW>;
-    using T = Tile<TW>;
-    constexpr int CPW = SU::CPW, QPP = SU::QPP;
-    constexpr int WP = T::WW * T::WH;
-    __shared__ float4 win[WP * QPP];
-    __shared__ float gw[CPW * WP];  // planar d_src window: lanes on neighbouring columns hit neighbouring banks
-    __shared__ int bb[16];
-    const int tid = threadIdx.x;
-    for (int i = tid; i < CPW * WP; i += 256) gw[i] = 0.f;
-    SU s;
-    s.init(a, win, bb);  // contains the barriers that also publish the zeroed gw
+struct Tap4 {
+    int x0, y0;
+    float w00, w01, w10, w11;
+};
 
-    const size_t hw = (size_t)a.h * a.w;
-    if (s.valid) {
-        float rf[CPW], dref[CPW];
-#pragma unroll
-        for (int k = 0; k < CPW; ++k) {
-            rf[k] = a.ref[((size_t)s.b * a.C + slot_channel<N>(k, a.G, s.gbase)) * hw + s.p];
-            dref[k] = 0.f;
+// Per-thread state of the hypothesis walk.
+template <bool FUSED>
+struct Walk {
+    CamMats cam;
+    float r0, r1, r2, wm1, hm1, rw, rh;
+    float A0, A1, A2, B0, B1, B2;  // c_i(dep) = dep * A_i + B_i
+    HypConst hc;
+    const float *hyp_p;  // !FUSED: &hyp[b, 0, y, x]
+    size_t hyp_stride;   // h*w
+    int sched_type, d0;
+
+    __device__ __forceinline__ float hypothesis(const float *itv, int k) const {
+        if (!FUSED) return hyp_p[(size_t)k * hyp_stride];
+        return md_hyp_eval(hc, itv[k - d0], sched_type);
+    }
+    __device__ __forceinline__ Tap4 tap_at(float dep) const {
+        float ix, iy;
+        if (kReferenceOpOrder) {
+            md_project_fast(cam, r0, r1, r2, dep, wm1, hm1, rw, rh, ix, iy);
+        } else {
+            // projective-linear in depth: c = dep * (P[:, :3] @ ray) + P[:, 3]; the [-1,1] normalise / un-normalise
+            // round trip of Project3D + grid_sample is the identity and is dropped
+            const float rz = md_rcp_nr(fmaf(dep, A2, B2));
+            ix = fmaf(dep, A0, B0) * rz;
+            iy = fmaf(dep, A1, B1) * rz;
         }
-        const float *gp = a.gout + (size_t)s.b * a.sb + (size_t)s.gbase * a.sg + s.p;
-        float *dsrcb = a.d_src + (size_t)s.b * a.C * hw;
-        float dnext = load_hyp(a, s.b, s.d0, s.p, s.prior_c, s.one_pf);
-        for (int d = s.d0; d < s.d1; ++d) {
-            const float dep = dnext;
-            if (d + 1 < s.d1) dnext = load_hyp(a, s.b, d + 1, s.p, s.prior_c, s.one_pf);
-            float gq[GS];
+        float fx = floorf(ix), fy = floorf(iy);
+        const float wx1 = ix - fx, wy1 = iy - fy, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+        // NaN -> far outside; the float->int conversion saturates for +-inf / huge values
+        fx = (ix == ix) ? fx : -1e9f;
+        fy = (iy == iy) ? fy : -1e9f;
+        Tap4 t;
+        t.x0 = (int)fminf(fmaxf(fx, -1e9f), 1e9f);
+        t.y0 = (int)fminf(fmaxf(fy, -1e9f), 1e9f);
+        t.w00 = wy0 * wx0; t.w01 = wy0 * wx1; t.w10 = wy1 * wx0; t.w11 = wy1 * wx1;
+        return t;
+    }
+};
+
+// Tap outside the staged window: zero when all four taps miss the image, else bounds-checked global loads.
+template <int CPW, int N>
+__device__ __noinline__ vecf<CPW> sample_slow(const float *__restrict__ srcb, int h, int w, int G, int gbase, int x0,
+                                               int y0, float w00, float w01, float w10, float w11) {
+    vecf<CPW> S = 0.f;
+    if (x0 < -1 || x0 >= w || y0 < -1 || y0 >= h) return S;
+    const size_t hw = (size_t)h * w;
+    const int x1 = x0 + 1, y1 = y0 + 1;
+    const bool vx0 = x0 >= 0, vx1 = x1 < w, vy0 = y0 >= 0, vy1 = y1 < h;
 #pragma unroll
-            for (int j = 0; j < GS; ++j) gq[j] = gp[(size_t)d * a.sd + (size_t)j * a.sg] / (float)N;
-            Proj pr = md_project(s.cam, s.r0, s.r1, s.r2, dep, a.w, a.h);
-            Tap t = md_make_tap(pr.ix, pr.iy, a.w, a.h);
-            float S[CPW];
-            bool in_win;
-            s.sample(a, win, t, S, in_win);
+    for (int k = 0; k < CPW; ++k) {
+        const float *pl = srcb + (size_t)slot_channel<N>(k, G, gbase) * hw;
+        float s = 0.f;
+        if (vx0 && vy0) s += pl[y0 * w + x0] * w00;
+        if (vx1 && vy0) s += pl[y0 * w + x1] * w01;
+        if (vx0 && vy1) s += pl[y1 * w + x0] * w10;
+        if (vx1 && vy1) s += pl[y1 * w + x1] * w11;
+        S[k] = s;
+    }
+    return S;
+}
+
+// d_src scatter for a cell outside the staged window (global float atomics, bounds checked).
+template <int CPW, int N>
+__device__ __noinline__ void scatter_slow(float *__restrict__ dsrcb, int h, int w, int G, int gbase, int x0, int y0,
+                                          vecf<CPW> a0, vecf<CPW> a1, vecf<CPW> a2, vecf<CPW> a3) {
+    const size_t hw = (size_t)h * w;
+    const int x1 = x0 + 1, y1 = y0 + 1;
+    const bool vx0 = x0 >= 0 && x0 < w, vx1 = x1 >= 0 && x1 < w, vy0 = y0 >= 0 && y0 < h, vy1 = y1 >= 0 && y1 < h;
+    if (!((vx0 || vx1) && (vy0 || vy1))) return;
 #pragma unroll
-            for (int k = 0; k < CPW; ++k) dref[k] += gq[k / N] * S[k];
-            const float wx0 = 1.f - t.wx1, wy0 = 1.f - t.wy1;
-            const float w00 = wy0 * wx0, w01 = wy0 * t.wx1, w10 = t.wy1 * wx0, w11 = t.wy1 * t.wx1;
-            if (in_win) {
-                const int o = (t.y0 - s.oy) * T::WW + (t.x0 - s.ox);
+    for (int k = 0; k < CPW; ++k) {
+        float *pl = dsrcb + (size_t)slot_channel<N>(k, G, gbase) * hw;
+        if (vx0 && vy0) unsafeAtomicAdd(pl + y0 * w + x0, a0[k]);
+        if (vx1 && vy0) unsafeAtomicAdd(pl + y0 * w + x1, a1[k]);
+        if (vx0 && vy1) unsafeAtomicAdd(pl + y1 * w + x0, a2[k]);
+        if (vx1 && vy1) unsafeAtomicAdd(pl + y1 * w + x1, a3[k]);
+    }
+}
+
+// Bilinear samples of the CPW staged channels at tap t ('zeros' padding comes from the zero-filled window).
+template <int CPW, int N, int TW>
+__device__ __forceinline__ vecf<CPW> sample_window(const float4 *win, const Tap4 &t, int ox, int oy,
+                                                   const float *__restrict__ srcb, int h, int w, int G, int gbase) {
+    using T = Tile<TW, CPW>;
+    constexpr int QPP = CPW / 4;
+    const int lx = t.x0 - ox, ly = t.y0 - oy;
+    const bool in_win = (unsigned)lx < (unsigned)(T::WW - 1) && (unsigned)ly < (unsigned)(T::WH - 1);
+    vecf<CPW> S;
+    if (in_win) {
+        const float4 *wp = win + ly * T::WW + lx;
 #pragma unroll
-                for (int k = 0; k < CPW; ++k) {
-                    const float v = gq[k / N] * rf[k];
-                    float *g = gw + k * WP + o;
-                    atomicAdd(g, v * w00);
-                    atomicAdd(g + 1, v * w01);
-                    atomicAdd(g + T::WW, v * w10);
-                    atomicAdd(g + T::WW + 1, v * w11);
-                }
-            } else {
-                const int x1 = t.x0 + 1, y1 = t.y0 + 1;
-                const bool vx0 = t.x0 >= 0 && t.x0 < a.w, vx1 = x1 >= 0 && x1 < a.w;
-                const bool vy0 = t.y0 >= 0 && t.y0 < a.h, vy1 = y1 >= 0 && y1 < a.h;
-                if ((vx0 || vx1) && (vy0 || vy1)) {
+        for (int q = 0; q < QPP; ++q) {
+            const float4 a00 = wp[q * T::WP], a01 = wp[q * T::WP + 1];
+            const float4 a10 = wp[q * T::WP + T::WW], a11 = wp[q * T::WP + T::WW + 1];
+            S[q * 4 + 0] = a00.x * t.w00 + a01.x * t.w01 + a10.x * t.w10 + a11.x * t.w11;
+            S[q * 4 + 1] = a00.y * t.w00 + a01.y * t.w01 + a10.y * t.w10 + a11.y * t.w11;
+            S[q * 4 + 2] = a00.z * t.w00 + a01.z * t.w01 + a10.z * t.w10 + a11.z * t.w11;
+            S[q * 4 + 3] = a00.w * t.w00 + a01.w * t.w01 + a10.w * t.w10 + a11.w * t.w11;
+        }
+    } else {
+        S = sample_slow<CPW, N>(srcb, h, w, G, gbase, t.x0, t.y0, t.w00, t.w01, t.w10, t.w11);
+    }
+    return S;
+}
+
+// Tile set-up shared by forward and backward: the thread's pixel and walk state, the window origin, and the
+// staged source window.  Returns false for threads outside the image (they still helped stage the window).
+template <int GS, int N, int TW, bool FUSED>
+__device__ __forceinline__ bool tile_setup(const float *__restrict__ src, const float *__restrict__ K,
+                                           const float *__restrict__ invK, const float *__restrict__ pose,
+                                           const float *__restrict__ hyp, const float *__restrict__ prior,
+                                           const float *__restrict__ ztrans, const CvDims &dm, float4 *win, int *bb,
+                                           float *itv, Walk<FUSED> &wk, int &b, int &gbase, int &p, int &d0, int &d1,
+                                           int &ox, int &oy) {
+    constexpr int CPW = GS * N, QPP = CPW / 4;
+    using T = Tile<TW, CPW>;
+    const int tid = threadIdx.x;
+    b = blockIdx.z / dm.dsplit;
+    const int ds = blockIdx.z % dm.dsplit;
+    gbase = blockIdx.y * GS;
+    const int tx0 = (blockIdx.x % dm.tiles_x) * TW, ty0 = (blockIdx.x / dm.tiles_x) * T::TH;
+    const int x = tx0 + tid % TW, y = ty0 + tid / TW;
+    const bool valid = x < dm.w && y < dm.h;
+    p = y * dm.w + x;
+    d0 = ds * dm.dper;
+    d1 = min(dm.D, d0 + dm.dper);
+    const size_t hw = (size_t)dm.h * dm.w;
+    wk.cam = md_load_cam(K + b * 16, invK + b * 16, pose + b * 16);
+    md_ray(wk.cam, (float)x, (float)y, wk.r0, wk.r1, wk.r2);
+    wk.A0 = wk.cam.P[0] * wk.r0 + wk.cam.P[1] * wk.r1 + wk.cam.P[2] * wk.r2; wk.B0 = wk.cam.P[3];
+    wk.A1 = wk.cam.P[4] * wk.r0 + wk.cam.P[5] * wk.r1 + wk.cam.P[6] * wk.r2; wk.B1 = wk.cam.P[7];
+    wk.A2 = wk.cam.P[8] * wk.r0 + wk.cam.P[9] * wk.r1 + wk.cam.P[10] * wk.r2; wk.B2 = wk.cam.P[11] + 1e-7f;
+    wk.wm1 = (float)(dm.w - 1); wk.hm1 = (float)(dm.h - 1);
+    wk.rw = 1.f / wk.wm1; wk.rh = 1.f / wk.hm1;
+    wk.sched_type = dm.sched_type;
+    wk.d0 = d0;
+    wk.hyp_stride = hw;
+    wk.hyp_p = nullptr;
+    wk.hc.a = 1.f; wk.hc.b = 0.f;
+    if (FUSED) {
+        const float one_pf = 1.f + (ztrans ? dm.scale_fac * ztrans[b] : dm.scale_fac);
+        const float c = valid ? prior[(size_t)b * hw + p] : 1.f;
+        wk.hc = md_hyp_const(c, one_pf, dm.sched_type);
+        for (int i = tid; i < d1 - d0; i += 256) itv[i] = md_hyp_itv(d0 + i, dm.D, dm.sched_type);
+        __syncthreads();
+    } else {
+        wk.hyp_p = hyp + (size_t)b * dm.D * hw + (valid ? p : 0);
+    }
+    // bounding box of the north-west taps at both ends of the hypothesis slice (u(d), v(d) are monotone in d
+    // between them unless c_z changes sign; stragglers take the global path)
+    int mnx = INT_MAX, mny = INT_MAX, mxx = INT_MIN, mxy = INT_MIN;
+    if (valid && d1 > d0) {
 #pragma unroll
-                    for (int k = 0; k < CPW; ++k) {
-                        const float v = gq[k / N] * rf[k];
-                        float *pl = dsrcb + (size_t)slot_channel<N>(k, a.G, s.gbase) * hw;
-                        if (vx0 && vy0) unsafeAtomicAdd(pl + t.y0 * a.w + t.x0, v * w00);
-                        if (vx1 && vy0) unsafeAtomicAdd(pl + t.y0 * a.w + x1, v * w01);
-                        if (vx0 && vy1) unsafeAtomicAdd(pl + y1 * a.w + t.x0, v * w10);
-                        if (vx1 && vy1) unsafeAtomicAdd(pl + y1 * a.w + x1, v * w11);
+        for (int e = 0; e < 2; ++e) {
+            const Tap4 t = wk.tap_at(wk.hypothesis(itv, e ? d1 - 1 : d0));
+            if (t.x0 >= -1 && t.x0 < dm.w && t.y0 >= -1 && t.y0 < dm.h) {
+                mnx = min(mnx, t.x0); mxx = max(mxx, t.x0 + 1);
+                mny = min(mny, t.y0); mxy = max(mxy, t.y0 + 1);
+            }
+        }
+    }
+    mnx = md_wave_min(mnx); mny = md_wave_min(mny); mxx = md_wave_max(mxx); mxy = md_wave_max(mxy);
+    const int wave = tid >> 6;
+    if ((tid & 63) == 0) { bb[wave * 4] = mnx; bb[wave * 4 + 1] = mny; bb[wave * 4 + 2] = mxx; bb[wave * 4 + 3] = mxy; }
+    __syncthreads();
+#pragma unroll
+    for (int wv = 0; wv < 4; ++wv) {
+        mnx = min(mnx, bb[wv * 4]); mny = min(mny, bb[wv * 4 + 1]);
+        mxx = max(mxx, bb[wv * 4 + 2]); mxy = max(mxy, bb[wv * 4 + 3]);
+    }
+    if (mnx > mxx) { mnx = tx0; mxx = tx0; mny = ty0; mxy = ty0; }  // nothing lands in the image
+    const int spanx = mxx - mnx + 1, spany = mxy - mny + 1;
+    ox = spanx <= T::WW ? mnx : mnx + (spanx - T::WW) / 2;
+    oy = spany <= T::WH ? mny : mny + (spany - T::WH) / 2;
+    // stage the window: consecutive threads -> consecutive columns (coalesced per channel plane)
+    const float *srcb = src + (size_t)b * dm.C * hw;
+    for (int idx = tid; idx < T::WP * QPP; idx += 256) {
+        const int wx = idx % T::WW, rest = idx / T::WW;
+        const int wy = rest % T::WH, q = rest / T::WH;
+        const int sx = ox + wx, sy = oy + wy;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (sx >= 0 && sx < dm.w && sy >= 0 && sy < dm.h) {
+            const size_t o = (size_t)sy * dm.w + sx;
+            v.x = srcb[(size_t)slot_channel<N>(q * 4 + 0, dm.G, gbase) * hw + o];
+            v.y = srcb[(size_t)slot_channel<N>(q * 4 + 1, dm.G, gbase) * hw + o];
+            v.z = srcb[(size_t)slot_channel<N>(q * 4 + 2, dm.G, gbase) * hw + o];
+            v.w = srcb[(size_t)slot_channel<N>(q * 4 + 3, dm.G, gbase) * hw + o];
+        }
+        win[q * T::WP + wy * T::WW + wx] = v;
+    }
+    __syncthreads();
+    return valid;
+}
+
+template <int GS, int N, int TW, bool FUSED, bool WIDE>
+__global__ __launch_bounds__(256) void costvol_fwd_kernel(const float *__restrict__ ref, const float *__restrict__ src,
+                                                          const float *__restrict__ K, const float *__restrict__ invK,
+                                                          const float *__restrict__ pose, const float *__restrict__ hyp,
+                                                          const float *__restrict__ prior,
+                                                          const float *__restrict__ ztrans, float *__restrict__ out,
+                                                          const CvDims dm) {
+    constexpr int CPW = GS * N, QPP = CPW / 4;
+    using T = Tile<TW, CPW>;
+    __shared__ float4 win[T::WP * QPP];
+    __shared__ float itv[ITV_MAX];
+    __shared__ int bb[16];
+    Walk<FUSED> wk;
+    int b, gbase, p, d0, d1, ox, oy;
+    if (!tile_setup<GS, N, TW, FUSED>(src, K, invK, pose, hyp, prior, ztrans, dm, win, bb, itv, wk, b, gbase, p, d0, d1,
+                                      ox, oy))
+        return;
+
+    const size_t hw = (size_t)dm.h * dm.w;
+    const float *srcb = src + (size_t)b * dm.C * hw;
+    vecf<CPW> rf;  // ref features with the 1/N of the group mean folded in
+#pragma unroll
+    for (int k = 0; k < CPW; ++k)
+        rf[k] = ref[((size_t)b * dm.C + slot_channel<N>(k, dm.G, gbase)) * hw + p] * (1.f / (float)N);
+
+    float *outp = out + (size_t)b * dm.sb + (size_t)gbase * dm.sg + (size_t)d0 * dm.sd + p;
+    // wide stores: lane 4i+m writes group m of each 4-group batch at pixels 4i..4i+3 (p is lane 4i+m's own pixel)
+    const long long wide_off = (long long)(threadIdx.x & 3) * dm.sg - (long long)(threadIdx.x & 3);
+    float dnext = wk.hypothesis(itv, d0);
+    for (int d = d0; d < d1; ++d) {
+        const float dep = dnext;
+        if (d + 1 < d1) dnext = wk.hypothesis(itv, d + 1);
+        const Tap4 t = wk.tap_at(dep);
+        const int lx = t.x0 - ox, ly = t.y0 - oy;
+        const bool in_win = (unsigned)lx < (unsigned)(T::WW - 1) && (unsigned)ly < (unsigned)(T::WH - 1);
+        // the quad transpose of the wide-store path needs every lane of the wave on the fast path
+        if (WIDE ? __all(in_win) : in_win) {
+            // channels go through in 16-byte quads (one LDS plane per quad: neighbouring lanes read neighbouring
+            // 16-byte slots, conflict free, and every tap address is the same base + an immediate offset);
+            // a group's output is emitted as soon as its N channels are in
+            const float4 *wp = win + ly * T::WW + lx;
+            const v2f w00 = t.w00, w01 = t.w01, w10 = t.w10, w11 = t.w11;  // broadcast pairs -> v_pk_fma_f32
+            float acc = 0.f;
+            float o4[4];
+#pragma unroll
+            for (int q = 0; q < QPP; ++q) {
+                const float4 a00 = wp[q * T::WP], a01 = wp[q * T::WP + 1];
+                const float4 a10 = wp[q * T::WP + T::WW], a11 = wp[q * T::WP + T::WW + 1];
+                // two channels per packed instruction (a quad's .xy / .zw sit in aligned register pairs)
+                const v2f lo = v2f{a00.x, a00.y} * w00 + v2f{a01.x, a01.y} * w01 + v2f{a10.x, a10.y} * w10 + v2f{a11.x, a11.y} * w11;
+                const v2f hi = v2f{a00.z, a00.w} * w00 + v2f{a01.z, a01.w} * w01 + v2f{a10.z, a10.w} * w10 + v2f{a11.z, a11.w} * w11;
+                const v2f plo = lo * v2f{rf[q * 4 + 0], rf[q * 4 + 1]}, phi = hi * v2f{rf[q * 4 + 2], rf[q * 4 + 3]};
+                const float S4[4] = {plo.x, plo.y, phi.x, phi.y};  // already multiplied by ref/N
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int k = q * 4 + e;
+                    acc += S4[e];
+                    if (k % N == N - 1) {
+                        const int j = k / N;  // group done
+                        if (WIDE) {
+                            o4[j % 4] = acc;
+                            if (j % 4 == 3) {
+                                // 4x4 transpose across each lane quad: lane 4i+m ends up with group (j-3+m) at
+                                // pixels 4i..4i+3, one 16-byte store per lane instead of four 4-byte ones
+                                quad_transpose(o4);
+                                float *dst = outp + (size_t)(j - 3) * dm.sg + wide_off;
+                                *reinterpret_cast<float4 *>(dst) = make_float4(o4[0], o4[1], o4[2], o4[3]);
+                            }
+                        } else {
+                            outp[(size_t)j * dm.sg] = acc;
+                        }
+                        acc = 0.f;
                     }
                 }
             }
+        } else {
+            const vecf<CPW> S = sample_window<CPW, N, TW>(win, t, ox, oy, srcb, dm.h, dm.w, dm.G, gbase);
+#pragma unroll
+            for (int j = 0; j < GS; ++j) {
+                float acc = 0.f;
+#pragma unroll
+                for (int i = 0; i < N; ++i) acc += S[j * N + i] * rf[j * N + i];
+                outp[(size_t)j * dm.sg] = acc;
+            }
         }
-        float *drp = a.d_ref + (size_t)s.b * a.C * hw + s.p;
+        outp += dm.sd;
+    }
+}
+
+template <int GS, int N, int TW, bool FUSED>
+__global__ __launch_bounds__(256) void costvol_bwd_kernel(const float *__restrict__ gout, const float *__restrict__ ref,
+                                                          const float *__restrict__ src, const float *__restrict__ K,
+                                                          const float *__restrict__ invK, const float *__restrict__ pose,
+                                                          const float *__restrict__ hyp, const float *__restrict__ prior,
+                                                          const float *__restrict__ ztrans, float *__restrict__ d_ref,
+                                                          float *__restrict__ d_src, const CvDims dm) {
+    constexpr int CPW = GS * N, QPP = CPW / 4;
+    using T = Tile<TW, CPW>;
+    constexpr int WP = T::WP;
+    __shared__ float4 win[WP * QPP];
+    __shared__ float gw[CPW * WP];  // planar d_src window: lanes on neighbouring columns hit neighbouring banks
+    __shared__ float itv[ITV_MAX];
+    __shared__ int bb[16];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < CPW * WP; i += 256) gw[i] = 0.f;
+    Walk<FUSED> wk;
+    int b, gbase, p, d0, d1, ox, oy;
+    const bool valid = tile_setup<GS, N, TW, FUSED>(src, K, invK, pose, hyp, prior, ztrans, dm, win, bb, itv, wk, b,
+                                                    gbase, p, d0, d1, ox, oy);  // its barriers publish the zeroed gw
+    const size_t hw = (size_t)dm.h * dm.w;
+    const float *srcb = src + (size_t)b * dm.C * hw;
+    float *dsrcb = d_src + (size_t)b * dm.C * hw;
+    if (valid) {
+        vecf<CPW> rf, dref = 0.f;
+#pragma unroll
+        for (int k = 0; k < CPW; ++k)
+            rf[k] = ref[((size_t)b * dm.C + slot_channel<N>(k, dm.G, gbase)) * hw + p] * (1.f / (float)N);
+        vecf<CPW> a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;  // pending d_src quad at cell (bx, by)
+        int bx = INT_MIN, by = INT_MIN;
+        const float *gp = gout + (size_t)b * dm.sb + (size_t)gbase * dm.sg + (size_t)d0 * dm.sd + p;
+        float dnext = wk.hypothesis(itv, d0);
+        for (int d = d0; d <= d1; ++d) {
+            Tap4 t;
+            vecf<CPW> gv = 0.f;
+            if (d < d1) {
+                const float dep = dnext;
+                if (d + 1 < d1) dnext = wk.hypothesis(itv, d + 1);
+                float gq[GS];
+#pragma unroll
+                for (int j = 0; j < GS; ++j) gq[j] = gp[(size_t)j * dm.sg];
+                gp += dm.sd;
+                t = wk.tap_at(dep);
+                const vecf<CPW> S = sample_window<CPW, N, TW>(win, t, ox, oy, srcb, dm.h, dm.w, dm.G, gbase);
+#pragma unroll
+                for (int k = 0; k < CPW; ++k) {
+                    dref[k] += gq[k / N] * S[k];
+                    gv[k] = gq[k / N] * rf[k];
+                }
+            } else {
+                t.x0 = INT_MIN; t.y0 = INT_MIN;  // sentinel iteration: forces the final flush
+                t.w00 = t.w01 = t.w10 = t.w11 = 0.f;
+            }
+            if (t.x0 != bx || t.y0 != by) {
+                if (bx != INT_MIN && !(dm.dbg & 1)) {
+                    const int lx = bx - ox, ly = by - oy;
+                    if ((unsigned)lx < (unsigned)(T::WW - 1) && (unsigned)ly < (unsigned)(T::WH - 1)) {
+                        float *g = gw + ly * T::WW + lx;
+#pragma unroll
+                        for (int k = 0; k < CPW; ++k) {
+                            atomicAdd(g + k * WP, a0[k]);
+                            atomicAdd(g + k * WP + 1, a1[k]);
+                            atomicAdd(g + k * WP + T::WW, a2[k]);
+                            atomicAdd(g + k * WP + T::WW + 1, a3[k]);
+                        }
+                    } else {
+                        scatter_slow<CPW, N>(dsrcb, dm.h, dm.w, dm.G, gbase, bx, by, a0, a1, a2, a3);
+                    }
+                }
+                bx = t.x0; by = t.y0;
+                a0 = 0.f; a1 = 0.f; a2 = 0.f; a3 = 0.f;
+            }
+            a0 += gv * t.w00; a1 += gv * t.w01; a2 += gv * t.w10; a3 += gv * t.w11;
+        }
+        float *drp = d_ref + (size_t)b * dm.C * hw + p;
 #pragma unroll
         for (int k = 0; k < CPW; ++k) {
-            float *o = drp + (size_t)slot_channel<N>(k, a.G, s.gbase) * hw;
-            if (a.dsplit == 1) *o = dref[k];
-            else unsafeAtomicAdd(o, dref[k]);
+            float *o = drp + (size_t)slot_channel<N>(k, dm.G, gbase) * hw;
+            const float v = dref[k] * (1.f / (float)N);  // the group mean's 1/N (rf carries it on the d_src side)
+            if (dm.dsplit == 1) *o = v;
+            else unsafeAtomicAdd(o, v);
         }
     }
     __syncthreads();
     // flush the d_src window (cells outside the image are grid_sample's zero padding: dropped)
-    float *dsrcb = a.d_src + (size_t)s.b * a.C * hw;
     for (int idx = tid; idx < CPW * WP; idx += 256) {
         const float v = gw[idx];
-        if (v == 0.f) continue;
+        if (v == 0.f || (dm.dbg & 2)) continue;
         const int k = idx / WP, cell = idx % WP;
-        const int sx = s.ox + cell % T::WW, sy = s.oy + cell / T::WW;
-        if (sx >= 0 && sx < a.w && sy >= 0 && sy < a.h)
-            unsafeAtomicAdd(dsrcb + (size_t)slot_channel<N>(k, a.G, s.gbase) * hw + (size_t)sy * a.w + sx, v);
+        const int sx = ox + cell % T::WW, sy = oy + cell / T::WW;
+        if (sx >= 0 && sx < dm.w && sy >= 0 && sy < dm.h)
+            unsafeAtomicAdd(dsrcb + (size_t)slot_channel<N>(k, dm.G, gbase) * hw + (size_t)sy * dm.w + sx, v);
     }
 }
 
@@ -320,58 +481,113 @@ int env_int(const char *name, int dflt) {
     return (e && *e) ? atoi(e) : dflt;
 }
 
+struct CvPtrs {
+    const float *gout, *ref, *src, *K, *invK, *pose, *hyp, *prior, *ztrans;
+    float *out, *d_ref, *d_src;
+};
+
 // Picks (GS, N, TW) and launches.  Supported: N = C/G in {1,2,4,8}, CPW = GS*N in {4,8,16}.
 template <bool BWD>
-int launch(CostvolArgs a, hipStream_t stream) {
-    const int N = a.C / a.G;
-    int GS = 0;
-    if (N == 1) GS = (a.G % 8 == 0) ? 8 : ((a.G % 4 == 0) ? 4 : 0);
-    else if (N == 2) GS = (a.G % 4 == 0) ? 4 : ((a.G % 2 == 0) ? 2 : 0);
-    else if (N == 4) GS = (a.G % 2 == 0) ? 2 : 1;
-    else if (N == 8) GS = 1;
-    if (GS == 0) {
-        md_set_error("costvol: unsupported channel grouping C=%d G=%d (need C/G in {1,2,4,8} and a group split)", a.C, a.G);
+int launch(const CvPtrs &q, CvDims dm, hipStream_t stream) {
+    const int N = dm.C / dm.G;
+    if (N != 1 && N != 2 && N != 4 && N != 8) {
+        md_set_error("costvol: unsupported channel grouping C=%d G=%d (C/G must be 1, 2, 4 or 8)", dm.C, dm.G);
         return MD_EINVAL;
     }
-    const int TW = (a.w % 64 == 0 && env_int("MD_COSTVOL_TW", 0) != 32) || env_int("MD_COSTVOL_TW", 0) == 64 ? 64 : 32;
+    // channels per workgroup: coordinates are computed once per (pixel, hypothesis) for all of them, but LDS per
+    // workgroup grows with it; 16 measured best for the forward at 48x160 (8: 68 us, 16: 61 us, 32: 70 us).  The
+    // backward keeps 4 x CPW scatter accumulators in registers, so it carries 8.
+    int cpw_target = env_int(BWD ? "MD_COSTVOL_CPW_BWD" : "MD_COSTVOL_CPW", BWD ? 8 : 16);
+    int GS = 0;
+    for (int cpw = cpw_target; cpw >= 4 && !GS; cpw /= 2)
+        if (cpw % N == 0 && dm.G % (cpw / N) == 0) GS = cpw / N;
+    for (int cpw = cpw_target * 2; cpw <= 32 && !GS; cpw *= 2)
+        if (cpw % N == 0 && dm.G % (cpw / N) == 0) GS = cpw / N;
+    if (GS == 0) {
+        md_set_error("costvol: no channel split for C=%d G=%d (need a multiple of 4 channels per workgroup)", dm.C, dm.G);
+        return MD_EINVAL;
+    }
+    const int CPW = GS * N;
+    const int tw_env = env_int("MD_COSTVOL_TW", 0);
+    const int TW = tw_env == 64 ? 64 : 32;
     const int TH = 256 / TW;
-    a.tiles_x = md_cdiv(a.w, TW);
-    const int tiles = a.tiles_x * md_cdiv(a.h, TH);
-    const int splits = a.G / GS;
-    // enough workgroups to fill 256 CUs several times over; each D slice re-stages its window
-    int dsplit = env_int("MD_COSTVOL_DSPLIT", 0);
+    dm.tiles_x = md_cdiv(dm.w, TW);
+    dm.dbg = env_int("MD_COSTVOL_DEBUG", 0);
+    const int tiles = dm.tiles_x * md_cdiv(dm.h, TH);
+    const int splits = dm.G / GS;
+    // D slices: every workgroup should be resident at once (no second, partially filled round), as close to
+    // the chip's slot count as the slicing allows.  Slots = 256 CUs x workgroups per CU by LDS (and 8 by waves).
+    int dsplit = env_int(BWD ? "MD_COSTVOL_DSPLIT_BWD" : "MD_COSTVOL_DSPLIT", 0);
     if (dsplit <= 0) {
-        long long wgs = (long long)tiles * splits * a.B;
-        dsplit = (int)((2048 + wgs - 1) / wgs);
-        int cap = a.D / 16 > 0 ? a.D / 16 : 1;
+        const int wp = (TW + (CPW >= 32 ? 8 : 16)) * (TH + (CPW >= 32 ? 4 : 8));
+        const long long lds = (long long)wp * CPW * 4 * (BWD ? 2 : 1) + ITV_MAX * 4 + 64;
+        long long per_cu = (160 * 1024) / lds;
+        if (per_cu > 8) per_cu = 8;
+        if (per_cu < 1) per_cu = 1;
+        const long long slots = 256 * per_cu, wgs = (long long)tiles * splits * dm.B;
+        dsplit = (int)(slots / wgs);
+        const int cap = dm.D / 8 > 0 ? dm.D / 8 : 1;  // at least 8 hypotheses per slice: staging must amortise
         if (dsplit > cap) dsplit = cap;
     }
-    if (dsplit > a.D) dsplit = a.D;
+    if (dsplit < md_cdiv(dm.D, ITV_MAX)) dsplit = md_cdiv(dm.D, ITV_MAX);  // slices fit the LDS interval table
+    if (dsplit > dm.D) dsplit = dm.D;
     if (dsplit < 1) dsplit = 1;
-    a.dsplit = dsplit;
-    a.dper = md_cdiv(a.D, dsplit);
-    a.dsplit = md_cdiv(a.D, a.dper);
-    dim3 grid(tiles, splits, a.B * a.dsplit), block(256);
+    dm.dper = md_cdiv(dm.D, dsplit);
+    dm.dsplit = md_cdiv(dm.D, dm.dper);
+    const dim3 grid(tiles, splits, dm.B * dm.dsplit), block(256);
+    // 16-byte stores need 4-pixel lane quads inside one row and 16-byte aligned planes
+    const bool wide = !BWD && env_int("MD_COSTVOL_WIDE", 0) && dm.w % 4 == 0 && dm.sb % 4 == 0 && dm.sd % 4 == 0 &&
+                      dm.sg % 4 == 0 && ((uintptr_t)q.out % 16) == 0;
+    (void)wide;
 
-#define MD_CV_LAUNCH(GS_, N_, TW_)                                                         \
-    do {                                                                                   \
-        if (BWD) hipLaunchKernelGGL((costvol_bwd_kernel<GS_, N_, TW_>), grid, block, 0, stream, a); \
-        else hipLaunchKernelGGL((costvol_fwd_kernel<GS_, N_, TW_>), grid, block, 0, stream, a);     \
+#define MD_CV_LAUNCH(GS_, N_, TW_, F_)                                                                                \
+    do {                                                                                                              \
+        if (BWD)                                                                                                      \
+            hipLaunchKernelGGL((costvol_bwd_kernel<GS_, N_, TW_, F_>), grid, block, 0, stream, q.gout, q.ref, q.src,  \
+                               q.K, q.invK, q.pose, q.hyp, q.prior, q.ztrans, q.d_ref, q.d_src, dm);                  \
+        else if (wide && (GS_) % 4 == 0)                                                                              \
+            hipLaunchKernelGGL((costvol_fwd_kernel<GS_, N_, TW_, F_, ((GS_) % 4 == 0)>), grid, block, 0, stream,      \
+                               q.ref, q.src, q.K, q.invK, q.pose, q.hyp, q.prior, q.ztrans, q.out, dm);               \
+        else                                                                                                          \
+            hipLaunchKernelGGL((costvol_fwd_kernel<GS_, N_, TW_, F_, false>), grid, block, 0, stream, q.ref, q.src,   \
+                               q.K, q.invK, q.pose, q.hyp, q.prior, q.ztrans, q.out, dm);                             \
     } while (0)
-#define MD_CV_TW(GS_, N_)                     \
-    do {                                      \
-        if (TW == 64) MD_CV_LAUNCH(GS_, N_, 64); \
-        else MD_CV_LAUNCH(GS_, N_, 32);       \
+#define MD_CV_F(GS_, N_, TW_)                        \
+    do {                                             \
+        if (q.hyp) MD_CV_LAUNCH(GS_, N_, TW_, false); \
+        else MD_CV_LAUNCH(GS_, N_, TW_, true);       \
+    } while (0)
+#define MD_CV_TW(GS_, N_)                  \
+    do {                                   \
+        if (TW == 64) MD_CV_F(GS_, N_, 64); \
+        else MD_CV_F(GS_, N_, 32);         \
     } while (0)
 
-    if (N == 1 && GS == 8) MD_CV_TW(8, 1);
-    else if (N == 1 && GS == 4) MD_CV_TW(4, 1);
-    else if (N == 2 && GS == 4) MD_CV_TW(4, 2);
-    else if (N == 2 && GS == 2) MD_CV_TW(2, 2);
-    else if (N == 4 && GS == 2) MD_CV_TW(2, 4);
-    else if (N == 4 && GS == 1) MD_CV_TW(1, 4);
-    else MD_CV_TW(1, 8);
+    bool launched = true;
+    switch (N * 100 + CPW) {
+        case 104: MD_CV_TW(4, 1); break;
+        case 108: MD_CV_TW(8, 1); break;
+        case 116: MD_CV_TW(16, 1); break;
+        case 132: MD_CV_TW(32, 1); break;
+        case 204: MD_CV_TW(2, 2); break;
+        case 208: MD_CV_TW(4, 2); break;
+        case 216: MD_CV_TW(8, 2); break;
+        case 232: MD_CV_TW(16, 2); break;
+        case 404: MD_CV_TW(1, 4); break;
+        case 408: MD_CV_TW(2, 4); break;
+        case 416: MD_CV_TW(4, 4); break;
+        case 432: MD_CV_TW(8, 4); break;
+        case 808: MD_CV_TW(1, 8); break;
+        case 816: MD_CV_TW(2, 8); break;
+        case 832: MD_CV_TW(4, 8); break;
+        default: launched = false;
+    }
+    if (!launched) {
+        md_set_error("costvol: no kernel for C/G=%d with %d channels per workgroup", N, CPW);
+        return MD_EINVAL;
+    }
 #undef MD_CV_TW
+#undef MD_CV_F
 #undef MD_CV_LAUNCH
     MD_CHECK_LAUNCH(BWD ? "md_costvol_bwd" : "md_costvol_fwd");
     return MD_OK;
@@ -386,7 +602,7 @@ int check_common(const char *fn, const void *ref, const void *src, const void *K
     MD_REQUIRE(C % G == 0, "%s: C=%d not divisible by G=%d", fn, C, G);
     MD_REQUIRE(hyp || D > 1, "%s: the fused schedule needs D > 1", fn);
     MD_REQUIRE(sched_type >= 0 && sched_type <= 2, "%s: bad schedule type %d", fn, sched_type);
-    MD_REQUIRE((long long)B * 65535 >= 1 && B <= 16384, "%s: batch too large", fn);
+    MD_REQUIRE(B <= 16384, "%s: batch too large", fn);
     return MD_OK;
 }
 
@@ -399,12 +615,14 @@ extern "C" int md_costvol_fwd(const float *ref, const float *src, const float *K
     int rc = check_common("md_costvol_fwd", ref, src, K, invK, pose, hyp, prior, sched_type, B, C, G, h, w, D);
     if (rc) return rc;
     MD_REQUIRE(out, "md_costvol_fwd: null output");
-    CostvolArgs a{};
-    a.ref = ref; a.src = src; a.K = K; a.invK = invK; a.pose = pose; a.hyp = hyp; a.prior = prior; a.ztrans = ztrans;
-    a.scale_fac = scale_fac; a.sched_type = sched_type;
-    a.B = B; a.C = C; a.G = G; a.h = h; a.w = w; a.D = D;
-    a.out = out; a.sb = out_sb; a.sd = out_sd; a.sg = out_sg;
-    return launch<false>(a, (hipStream_t)stream);
+    CvPtrs q{};
+    q.ref = ref; q.src = src; q.K = K; q.invK = invK; q.pose = pose; q.hyp = hyp; q.prior = prior; q.ztrans = ztrans;
+    q.out = out;
+    CvDims dm{};
+    dm.scale_fac = scale_fac; dm.sched_type = sched_type;
+    dm.B = B; dm.C = C; dm.G = G; dm.h = h; dm.w = w; dm.D = D;
+    dm.sb = out_sb; dm.sd = out_sd; dm.sg = out_sg;
+    return launch<false>(q, dm, (hipStream_t)stream);
 }
 
 extern "C" int md_costvol_bwd(const float *gout, long long g_sb, long long g_sd, long long g_sg, const float *ref,
@@ -415,14 +633,15 @@ extern "C" int md_costvol_bwd(const float *gout, long long g_sb, long long g_sd,
     int rc = check_common("md_costvol_bwd", ref, src, K, invK, pose, hyp, prior, sched_type, B, C, G, h, w, D);
     if (rc) return rc;
     MD_REQUIRE(gout && d_ref && d_src, "md_costvol_bwd: null gradient tensor");
-    CostvolArgs a{};
-    a.ref = ref; a.src = src; a.K = K; a.invK = invK; a.pose = pose; a.hyp = hyp; a.prior = prior; a.ztrans = ztrans;
-    a.scale_fac = scale_fac; a.sched_type = sched_type;
-    a.B = B; a.C = C; a.G = G; a.h = h; a.w = w; a.D = D;
-    a.gout = gout; a.sb = g_sb; a.sd = g_sd; a.sg = g_sg;
-    a.d_ref = d_ref; a.d_src = d_src;
+    CvPtrs q{};
+    q.gout = gout; q.ref = ref; q.src = src; q.K = K; q.invK = invK; q.pose = pose; q.hyp = hyp; q.prior = prior;
+    q.ztrans = ztrans; q.d_ref = d_ref; q.d_src = d_src;
+    CvDims dm{};
+    dm.scale_fac = scale_fac; dm.sched_type = sched_type;
+    dm.B = B; dm.C = C; dm.G = G; dm.h = h; dm.w = w; dm.D = D;
+    dm.sb = g_sb; dm.sd = g_sd; dm.sg = g_sg;
     const size_t bytes = sizeof(float) * (size_t)B * C * h * w;
     MD_CHECK_HIP(hipMemsetAsync(d_src, 0, bytes, (hipStream_t)stream));
     MD_CHECK_HIP(hipMemsetAsync(d_ref, 0, bytes, (hipStream_t)stream));
-    return launch<true>(a, (hipStream_t)stream);
+    return launch<true>(q, dm, (hipStream_t)stream);
 }

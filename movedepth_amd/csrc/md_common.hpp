@@ -97,17 +97,52 @@ __device__ __forceinline__ Proj md_project(const CamMats &m, float r0, float r1,
     return p;
 }
 
-// Depth hypothesis k of D for prior depth c (layers.py:261-279 / 375-393).  one_pf = 1 + scale_fac[*ztrans].
+// v_rcp_f32 (1 ulp) + one Newton step: within 1 ulp of the IEEE quotient at a fifth of its instruction count.
+__device__ __forceinline__ float md_rcp_nr(float x) {
+    float r = __builtin_amdgcn_rcpf(x);
+    return fmaf(fmaf(-x, r, 1.f), r, r);
+}
+
+// Depth-range schedule (layers.py:261-279 / 375-393), split into its per-pixel constants and the per-bin
+// evaluation so the cost-volume kernels can keep the constants in registers across the hypothesis loop.
+// The standalone schedule kernel and the fused in-kernel schedule share this code: bit-identical hypotheses.
+struct HypConst {
+    float a, b;  // inverse: hyp = 1/(a + b*itv), a = 1/dmax, b = 1/dmin - 1/dmax;  linear/log: hyp = a + b*itv
+};
+__device__ __forceinline__ HypConst md_hyp_const(float c, float one_pf, int type) {
+    const float dmin = c / one_pf, dmax = c * one_pf;
+    HypConst h;
+    if (type == MD_SCHED_INVERSE) { h.a = 1.f / dmax; h.b = 1.f / dmin - 1.f / dmax; }
+    else { h.a = dmin; h.b = dmax - dmin; }
+    return h;
+}
+// interval position of bin k: k/(D-1), or the reference's fp32 log spacing (layers.py:274-278)
+__device__ __forceinline__ float md_hyp_itv(int k, int D, int type) {
+    return (type == MD_SCHED_LOG) ? expf(logf(0.1f) + logf(1.f / 0.1f) * (float)k / (float)(D - 1))
+                                  : (float)k / (float)(D - 1);
+}
+__device__ __forceinline__ float md_hyp_eval(const HypConst &h, float itv, int type) {
+    const float v = h.a + h.b * itv;
+    return type == MD_SCHED_INVERSE ? md_rcp_nr(v) : v;
+}
 __device__ __forceinline__ float md_hypothesis(float c, float one_pf, int k, int D, int type) {
-    float dmin = c / one_pf, dmax = c * one_pf;
-    if (type == MD_SCHED_INVERSE) {
-        float itv = (float)k / (float)(D - 1);
-        float inv = 1.f / dmax + (1.f / dmin - 1.f / dmax) * itv;
-        return 1.f / inv;
-    }
-    float itv = (type == MD_SCHED_LOG) ? expf(logf(0.1f) + logf(1.f / 0.1f) * (float)k / (float)(D - 1))
-                                       : (float)k / (float)(D - 1);
-    return dmin + (dmax - dmin) * itv;
+    return md_hyp_eval(md_hyp_const(c, one_pf, type), md_hyp_itv(k, D, type), type);
+}
+
+// Hot-loop projection for the plane sweep: same operation order as md_project, with the two perspective
+// divides and the two /(size-1) done as multiplications by reciprocals (rw = 1/(w-1), rh = 1/(h-1) are IEEE
+// quotients computed once).  Deviates from md_project by <= ~2 ulp of the pixel coordinate.
+__device__ __forceinline__ void md_project_fast(const CamMats &m, float r0, float r1, float r2, float d, float wm1,
+                                                float hm1, float rw, float rh, float &ix, float &iy) {
+    const float X = d * r0, Y = d * r1, Z = d * r2;
+    const float c0 = m.P[0] * X + m.P[1] * Y + m.P[2] * Z + m.P[3];
+    const float c1 = m.P[4] * X + m.P[5] * Y + m.P[6] * Z + m.P[7];
+    const float c2 = m.P[8] * X + m.P[9] * Y + m.P[10] * Z + m.P[11];
+    const float rz = md_rcp_nr(c2 + 1e-7f);
+    const float gx = ((c0 * rz) * rw - 0.5f) * 2.f;
+    const float gy = ((c1 * rz) * rh - 0.5f) * 2.f;
+    ix = ((gx + 1.f) * 0.5f) * wm1;
+    iy = ((gy + 1.f) * 0.5f) * hm1;
 }
 
 // Bilinear tap set.  x0,y0 = north-west tap; wx1, wy1 = weights of the east / south taps.

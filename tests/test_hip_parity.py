@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import assert_close, load_golden, relerr
+from conftest import assert_close, assert_close_knife_edge, load_golden, relerr
 
 pytestmark = pytest.mark.gpu
 
@@ -171,7 +171,7 @@ def test_costvol_full_size_properties(ops):
     v = ops.costvol_grouped(r, s, K, invK, pose, G, **kw)
     g = torch.randn_like(v)
     (v * g).sum().backward()
-    lhs = float((v.double() * g.double()).sum())
+    lhs = float((v.detach().double() * g.double()).sum())
     assert abs(float((r.double() * r.grad.double()).sum()) - lhs) < 1e-4 * abs(lhs)
     assert abs(float((s.double() * s.grad.double()).sum()) - lhs) < 1e-4 * abs(lhs)
 
@@ -197,7 +197,9 @@ def test_warp_vs_oracle_fullres(ops, oracle_lib):
     depth = (2 + 20 * smooth_field(rng, (B, 1, H, W), 16)).astype(np.float32)
     K, invK = kitti_K(H, W, B)
     T = rand_pose(oracle_lib, rng, B, 0.01, 0.1)
-    gout = rng.standard_normal((B, 3, H, W)).astype(np.float32)
+    # a smooth upstream gradient: with white noise d_T is a sqrt(N)-cancelling sum in which the few samples that
+    # sit on a texel boundary (see assert_close_knife_edge) dominate the difference
+    gout = smooth_field(rng, (B, 3, H, W), 8, 0.2, 1.0)
     exp, exp_pix = oracle_lib.warp(img, depth, K, invK, T)
     exp_dd, exp_dT = oracle_lib.warp_bwd(gout, img, depth, K, invK, T)
     d, t = dev(depth, True), dev(T, True)
@@ -205,8 +207,8 @@ def test_warp_vs_oracle_fullres(ops, oracle_lib):
     assert_close(host(pix), exp_pix, rtol=1e-5)
     assert_close(host(out), exp)
     (out * dev(gout)).sum().backward()
-    assert_close(host(d.grad).reshape(exp_dd.shape), exp_dd, rtol=2e-4, atol_scale=5e-3)
-    assert_close(host(t.grad), exp_dT, rtol=2e-4)
+    assert_close_knife_edge(host(d.grad).reshape(exp_dd.shape), exp_dd, rtol=2e-4, what="d_depth")
+    assert_close(host(t.grad), exp_dT, rtol=2e-4, what="d_T")
 
 
 @pytest.mark.parametrize("hw", [(4, 8), (8, 16), (16, 32), (32, 64)])

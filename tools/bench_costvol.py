@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the plane-sweep kernels at BASELINE config 2 (B=6, 48x160, D=96, C=32, G=16, fp32).
+Prints time per launch and algorithmic GB/s (bytes model of SURVEY 8d / DESIGN.md).  GPU only."""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from movedepth_amd import ops  # noqa: E402
+
+
+def time_fn(fn, iters=50, warm=10):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) * 1e3 / iters  # us
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--B", type=int, default=6)
+    ap.add_argument("--h", type=int, default=48)
+    ap.add_argument("--w", type=int, default=160)
+    ap.add_argument("--D", type=int, default=96)
+    ap.add_argument("--C", type=int, default=32)
+    ap.add_argument("--G", type=int, default=16)
+    ap.add_argument("--fused", type=int, default=1)
+    ap.add_argument("--layout", default="bgd")
+    ap.add_argument("--iters", type=int, default=50)
+    a = ap.parse_args()
+    B, h, w, D, C, G = a.B, a.h, a.w, a.D, a.C, a.G
+    torch.manual_seed(0)
+    dev = "cuda"
+    K = torch.tensor([[0.58 * w, 0, 0.5 * w, 0], [0, 1.92 * h, 0.5 * h, 0], [0, 0, 1, 0], [0, 0, 0, 1]], device=dev).repeat(B, 1, 1)
+    invK = torch.linalg.pinv(K)
+    ref = torch.randn(B, C, h, w, device=dev, requires_grad=True)
+    src = torch.randn(B, C, h, w, device=dev, requires_grad=True)
+    prior = 2 + 20 * torch.rand(B, 1, h, w, device=dev)
+    pose = torch.eye(4, device=dev).repeat(B, 1, 1)
+    pose[:, 0, 3], pose[:, 2, 3] = 0.05, 0.03
+    hyp = ops.schedule_depth_range(prior, D, 0.3)
+    kw = dict(prior=prior, ndepth=D, scale_fac=0.3) if a.fused else dict(depth_priors=hyp)
+    vol = ops.costvol_grouped(ref, src, K, invK, pose, G, layout=a.layout, **kw)
+    g = torch.randn_like(vol)
+
+    def fwd():
+        with torch.no_grad():
+            ops.costvol_grouped(ref, src, K, invK, pose, G, layout=a.layout, **kw)
+
+    def bwd():
+        vol.backward(g, retain_graph=True)
+
+    hyp_bytes = 4 * B * h * w if a.fused else 4 * B * D * h * w
+    fbytes = 2 * 4 * B * C * h * w + hyp_bytes + 4 * B * D * G * h * w + 192 * B
+    bbytes = 4 * B * D * G * h * w + 2 * 4 * B * C * h * w + hyp_bytes + 2 * 4 * B * C * h * w
+    big = torch.empty_like(vol.contiguous())
+    t_fill = time_fn(lambda: big.zero_(), a.iters)
+    src_big = torch.randn_like(big)
+    t_copy = time_fn(lambda: big.copy_(src_big), a.iters)
+    print("  ref: zero_ of %.0f MB %.1f us (%.0f GB/s); copy_ %.1f us (%.0f GB/s r+w)" % (
+        big.numel() * 4 / 1e6, t_fill, big.numel() * 4 / t_fill / 1e3, t_copy, 2 * big.numel() * 4 / t_copy / 1e3))
+    tf = time_fn(fwd, a.iters)
+    tb = time_fn(bwd, a.iters)
+    env = {k: v for k, v in os.environ.items() if k.startswith("MD_")}
+    print("costvol B=%d %dx%d D=%d C=%d G=%d fused=%d layout=%s env=%s" % (B, h, w, D, C, G, a.fused, a.layout, env))
+    print("  fwd %8.1f us  %7.1f MB  %7.0f GB/s (%.1f%% of 8 TB/s)" % (tf, fbytes / 1e6, fbytes / tf / 1e3, fbytes / tf / 1e3 / 80))
+    print("  bwd %8.1f us  %7.1f MB  %7.0f GB/s (%.1f%% of 8 TB/s)  [includes 2 memsets + autograd glue]" % (tb, bbytes / 1e6, bbytes / tb / 1e3, bbytes / tb / 1e3 / 80))
+
+
+if __name__ == "__main__":
+    main()
