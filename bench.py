@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""Headline benchmark (BASELINE.json): train-step images/s at 192x640, D=96 (config 2: ResNet-18, batch 6 per
+GPU, fp32, synthetic KITTI-shaped frames resident in HBM) + the plane-sweep kernel's HBM roofline fraction.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
+        bench.py --gpus N --steps K --warmup W          # one rank per GPU, RCCL gradient all-reduce
+
+A step = Trainer.process_batch + backward + optimizer step on one batch.  Prints ONE JSON line on rank 0.
+`roofline`: md_costvol_fwd timed live with HIP events (torch's current stream = the launch stream) inside the
+timed region; algorithmic bytes per launch from DESIGN.md's model.  `cpu_baseline`: the C oracle (a port of the
+reference's CPU path, NOT the product) on a bounded sample, N=1 rank 0 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (guides/MI355X_MICROARCH.md)
+
+
+def costvol_fwd_bytes(B, C, G, h, w, D, fused):
+    """ref + src features, hypotheses (or the prior when the schedule is fused), grouped volume, K/invK/T."""
+    hyp = 4 * B * h * w if fused else 4 * B * D * h * w
+    return 2 * 4 * B * C * h * w + hyp + 4 * B * D * G * h * w + 192 * B
+
+
+def cpu_baseline(opt):
+    """Hot path of ONE sample of the workload (1/6 of a batch) through the C oracle, all host threads."""
+    import numpy as np
+
+    import oracle
+
+    rng = np.random.default_rng(0)
+    H, W, D, C, G = opt.height, opt.width, opt.num_depth_bins, 32, opt.reg3d_c
+    h, w = H // 4, W // 4
+    f32 = np.float32
+    ref, src = rng.standard_normal((1, C, h, w)).astype(f32), rng.standard_normal((1, C, h, w)).astype(f32)
+    Kq = np.array([[0.58 * w, 0, 0.5 * w, 0], [0, 1.92 * h, 0.5 * h, 0], [0, 0, 1, 0], [0, 0, 0, 1]], f32)[None]
+    K0 = np.array([[0.58 * W, 0, 0.5 * W, 0], [0, 1.92 * H, 0.5 * H, 0], [0, 0, 1, 0], [0, 0, 0, 1]], f32)[None]
+    iKq, iK0 = np.linalg.pinv(Kq[0]).astype(f32)[None], np.linalg.pinv(K0[0]).astype(f32)[None]
+    T = oracle.transformation_from_parameters(np.array([[0.0, 0.01, 0.0]], f32), np.array([[0.05, 0.0, 0.03]], f32))
+    prior = (2 + 20 * rng.random((1, 1, h, w))).astype(f32)
+    img, tgt = rng.random((1, 3, H, W), dtype=f32), rng.random((1, 3, H, W), dtype=f32)
+    depth = (2 + 20 * rng.random((1, 1, H, W))).astype(f32)
+    gvol = rng.standard_normal((1, D, G, h, w)).astype(f32)
+    gl = rng.standard_normal((1, 1, H, W)).astype(f32)
+
+    def one_sample():
+        hyp = oracle.schedule_depth_range(prior, D, 0.3, None, "inverse")
+        for _ in range(2):  # plain + mask-augmented pass
+            oracle.costvol_grouped(ref, src, Kq, iKq, hyp, T, G)
+            oracle.costvol_grouped_bwd(gvol, ref, src, Kq, iKq, hyp, T)
+        for _ in range(12):  # 8 mono + 2 MVS + 2 fuse warps, each with its SSIM+L1 loss, forward and backward
+            warped, _ = oracle.warp(img, depth, K0, iK0, T)
+            oracle.reproj_loss(warped, tgt)
+            gp = oracle.reproj_loss_bwd(gl, warped, tgt)
+            oracle.warp_bwd(gp, img, depth, K0, iK0, T)
+        for _ in range(2):  # identity losses
+            oracle.reproj_loss(img, tgt)
+        for s in range(4):
+            oracle.smooth_loss(depth[:, :, ::2 ** s, ::2 ** s], img[:, :, ::2 ** s, ::2 ** s], True)
+
+    one_sample()  # warm
+    t0 = time.time()
+    n = 0
+    while n < 2 or (time.time() - t0 < 10.0 and n < 50):
+        one_sample()
+        n += 1
+    dt = (time.time() - t0) / n
+    return {"value": 1.0 / dt, "unit": "images/s (hot path only, no conv nets)", "cores": oracle.num_threads(),
+            "kind": "port",
+            "sample": "1 sample (1/6 batch) of config 2: 2x cost volume fwd+bwd (48x160, D=%d, C=32->G=%d), 12x "
+                      "warp+SSIM/L1 fwd+bwd at %dx%d, identity + smoothness losses; C oracle with OpenMP, %d runs, "
+                      "%.2f s each" % (D, G, H, W, n, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch_per_gpu", type=int, default=6)
+    ap.add_argument("--no_cpu_baseline", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus > 1 and world != a.gpus:
+        raise SystemExit("launch --gpus %d with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (a.gpus, a.gpus, world))
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+
+    from movedepth_amd import ops
+    from movedepth_amd.options import MovedepthOptions
+    from movedepth_amd.synthetic import make_inputs
+    from movedepth_amd.trainer import Trainer
+
+    argv = ["--height", "192", "--width", "640", "--num_depth_bins", "96", "--batch_size", str(a.batch_per_gpu),
+            "--res_arch", "18", "--prior_scale", "2", "--convex_up", "--weights_init", "scratch", "--learning_rate", "2e-4",
+            "--local_rank", str(local_rank)]
+    if world > 1:
+        argv.append("--ddp")
+    opt = MovedepthOptions().parse(argv)
+    torch.manual_seed(1234 + rank)
+    import numpy as np
+
+    np.random.seed(1234 + rank)
+    trainer = Trainer(opt)
+    trainer.set_train()
+    dev = trainer.device
+    inputs = make_inputs(opt.batch_size, opt.height, opt.width, opt.frame_ids, seed=rank, device=dev)  # resident in HBM
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        trainer.train_step(dict(inputs))
+    ops.enable_kernel_timing(["md_costvol_fwd", "md_costvol_bwd"])
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        _, losses = trainer.train_step(dict(inputs))
+    barrier()
+    elapsed = time.perf_counter() - t0
+    loss_val = float(losses["loss"])
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    times = ops.kernel_times_us()
+
+    if rank == 0:
+        gb = opt.batch_size * world
+        h, w = opt.height // 4, opt.width // 4
+        fbytes = costvol_fwd_bytes(opt.batch_size, 32, opt.reg3d_c, h, w, opt.num_depth_bins, fused=True)
+        kt = times.get("md_costvol_fwd", {})
+        ach = fbytes / (kt["avg_us"] * 1e-6) / 1e9 if kt else None
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "costvol_fwd_pmc.json")
+        if os.path.exists(pmc):
+            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+        out = {
+            "metric": "train-step images/sec at 192x640, D=96; cost-volume HBM GB/s vs roofline",
+            "value": gb * a.steps / elapsed, "unit": "images/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE config %d: KITTI 192x640, ResNet18, D=96, batch %d/GPU, fp32, 2-frame cost "
+                                   "volume, process_batch+backward+Adam" % (2 if world == 1 else 3, opt.batch_size),
+                       "global_batch": gb, "parallelism": "dp%d" % world, "final_loss": loss_val},
+            "roofline": {"bound": "hbm", "kernel": "md_costvol_fwd (plane-sweep cost volume, fused schedule + group mean)",
+                         "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (ach / HBM_PEAK_GBS) if ach else None,
+                         "traffic": traffic, "algorithmic_bytes_per_launch": fbytes,
+                         "avg_launch_us": kt.get("avg_us"), "launches_timed": kt.get("launches"),
+                         "bwd_avg_launch_us": times.get("md_costvol_bwd", {}).get("avg_us")},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(opt)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

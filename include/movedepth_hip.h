@@ -55,31 +55,32 @@ int md_schedule_depth_range(const float *prior, const float *ztrans, int B, int 
  *   ref, src [B,C,h,w]; K, invK, pose [B,4,4] (scale-`prior_scale` intrinsics, pose = pose[:,0]);
  *   hypotheses: either hyp [B,D,h,w], or hyp == NULL and the schedule fused in from
  *   prior [B,1,h,w] (+ ztrans/scale_fac/sched_type as in md_schedule_depth_range; same arithmetic).
- *   out element (b,d,g,y,x) is written at out[b*out_sb + d*out_sd + g*out_sg + y*w + x]
- *   (strides in floats), so the volume can be laid out (B,D,G,h,w) like the reference or (B,G,D,h,w)
- *   as the 3-D regulariser consumes it (resnet_encoder.py:257) without a permute copy.
+ *   out element (b,d,g,y,x) is written at out[b*out_sb + d*out_sd + g*out_sg + (y*w + x)*out_sp]
+ *   (strides in floats), so the volume can be laid out (B,D,G,h,w) like the reference (sp = 1), (B,G,D,h,w)
+ *   as the 3-D regulariser permutes it (resnet_encoder.py:257), or channels-last (B,D,h,w,G) (sg = 1, sp = G),
+ *   the layout MIOpen's fast 3-D convolutions take -- without a permute copy in any case.
  */
 int md_costvol_fwd(const float *ref, const float *src, const float *K, const float *invK, const float *pose,
                    const float *hyp, const float *prior, const float *ztrans, float scale_fac, int sched_type,
                    int B, int C, int G, int h, int w, int D, float *out, long long out_sb, long long out_sd,
-                   long long out_sg, md_stream_t stream);
+                   long long out_sg, long long out_sp, md_stream_t stream);
 
 /* Autograd of md_costvol_fwd w.r.t. ref and src (the sampling grid is under no_grad, layers.py:784).
- * gout addressed with the same three strides; d_ref, d_src [B,C,h,w] are overwritten. */
-int md_costvol_bwd(const float *gout, long long g_sb, long long g_sd, long long g_sg, const float *ref,
+ * gout addressed with the same four strides; d_ref, d_src [B,C,h,w] are overwritten. */
+int md_costvol_bwd(const float *gout, long long g_sb, long long g_sd, long long g_sg, long long g_sp, const float *ref,
                    const float *src, const float *K, const float *invK, const float *pose, const float *hyp,
                    const float *prior, const float *ztrans, float scale_fac, int sched_type, int B, int C, int G,
                    int h, int w, int D, float *d_ref, float *d_src, md_stream_t stream);
 
 /* ---- frame-confidence fusion --------------------------------------------------------------
  * trainer.py:349-363: w_f = max_G softmax_G(mean_D vol_f); out = sum_f w_f vol_f / (1e-8 + sum_f w_f).
- * vols: N device pointers (host array) to grouped volumes addressed with (sb, sd, sg) strides, as is out.
+ * vols: N device pointers (host array) to grouped volumes addressed with (sb, sd, sg, sp) strides, as is out.
  * weights [N,B,h,w] may be NULL. */
 int md_fuse_fwd(const float *const *vols, int N, int B, int D, int G, int hw, long long sb, long long sd,
-                long long sg, float *out, float *weights, md_stream_t stream);
+                long long sg, long long sp, float *out, float *weights, md_stream_t stream);
 /* Autograd of md_fuse_fwd (the weights are not detached in the reference). d_vols: N pointers. */
 int md_fuse_bwd(const float *gout, const float *const *vols, int N, int B, int D, int G, int hw, long long sb,
-                long long sd, long long sg, float *const *d_vols, md_stream_t stream);
+                long long sd, long long sg, long long sp, float *const *d_vols, md_stream_t stream);
 
 /* ---- reprojection warp ----------------------------------------------------------------------
  * generate_images_pred / compute_fuse_losses warp (trainer.py:501-507, 519-529, 575-580):

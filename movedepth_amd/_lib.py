@@ -21,11 +21,11 @@ SIGNATURES = {
     "md_abi_version": (_i, []),
     "md_schedule_depth_range": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp]),
     "md_costvol_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _i, _i, _i, _vp, _ll, _ll,
-                           _ll, _vp]),
-    "md_costvol_bwd": (_i, [_vp, _ll, _ll, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _i, _i,
-                           _i, _vp, _vp, _vp]),
-    "md_fuse_fwd": (_i, [_vp, _i, _i, _i, _i, _i, _ll, _ll, _ll, _vp, _vp, _vp]),
-    "md_fuse_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _ll, _ll, _ll, _vp, _vp]),
+                           _ll, _ll, _vp]),
+    "md_costvol_bwd": (_i, [_vp, _ll, _ll, _ll, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _i,
+                           _i, _i, _vp, _vp, _vp]),
+    "md_fuse_fwd": (_i, [_vp, _i, _i, _i, _i, _i, _ll, _ll, _ll, _ll, _vp, _vp, _vp]),
+    "md_fuse_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _ll, _ll, _ll, _ll, _vp, _vp]),
     "md_warp_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "md_warp_bwd_ws_bytes": (_sz, [_i, _i, _i]),
     "md_warp_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),

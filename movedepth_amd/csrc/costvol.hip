@@ -44,10 +44,10 @@ struct CvDims {
     float scale_fac;
     int sched_type;
     int B, C, G, h, w, D;
-    int dsplit, dper;
-    int tiles_x;
+    int tiles_x, tiles, splits;  // pixel tiles per sample (x, total) and channel splits
+    int items;                   // B * tiles * splits work items of D hypotheses each
     int dbg;  // tuning only (MD_COSTVOL_DEBUG bitmask); 0 in production
-    long long sb, sd, sg;
+    long long sb, sd, sg, sp;
 };
 
 // Window = tile + epipolar reach.  The reach shrinks when a workgroup carries 32 channels (128 B per pixel)
@@ -71,26 +71,23 @@ __device__ __forceinline__ int slot_channel(int k, int G, int gbase) {
     return (k % N) * G + gbase + k / N;
 }
 
-// In-register 4x4 transpose across the four lanes of a quad (two DPP quad_perm butterfly stages, no LDS):
-// before, lane j holds v[r] = M[j][r]; after, lane j holds v[r] = M[r][j].
-template <int CTRL>
-__device__ __forceinline__ float quad_perm(float x) {
-    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), CTRL, 0xF, 0xF, true));
-}
-__device__ __forceinline__ void quad_transpose(float (&v)[4]) {
-    const int lane = threadIdx.x;
-    {   // exchange with lane^1 (quad_perm [1,0,3,2]), registers r <-> r^1
-        const float s0 = quad_perm<0xB1>(v[0]), s1 = quad_perm<0xB1>(v[1]), s2 = quad_perm<0xB1>(v[2]), s3 = quad_perm<0xB1>(v[3]);
-        const bool odd = lane & 1;
-        const float n0 = odd ? s1 : v[0], n1 = odd ? v[1] : s0, n2 = odd ? s3 : v[2], n3 = odd ? v[3] : s2;
-        v[0] = n0; v[1] = n1; v[2] = n2; v[3] = n3;
-    }
-    {   // exchange with lane^2 (quad_perm [2,3,0,1]), registers r <-> r^2
-        const float s0 = quad_perm<0x4E>(v[0]), s1 = quad_perm<0x4E>(v[1]), s2 = quad_perm<0x4E>(v[2]), s3 = quad_perm<0x4E>(v[3]);
-        const bool hi = lane & 2;
-        const float n0 = hi ? s2 : v[0], n1 = hi ? s3 : v[1], n2 = hi ? v[2] : s0, n3 = hi ? v[3] : s1;
-        v[0] = n0; v[1] = n1; v[2] = n2; v[3] = n3;
-    }
+// A segment = hypotheses [d0, d1) of one work item (sample, pixel tile, channel split).  The grid is sized to
+// the chip's workgroup slots and every workgroup takes an equal, contiguous share of the items x D hypothesis
+// steps (a workgroup's share may span two items): perfectly balanced for any B, image size and D, no tail round.
+struct Seg {
+    int b, tile, gs, d0, d1;
+};
+__device__ __forceinline__ bool next_segment(const CvDims &dm, long long &lo, long long hi, Seg &sg) {
+    if (lo >= hi) return false;
+    const int item = (int)(lo / dm.D);
+    sg.d0 = (int)(lo % dm.D);
+    const long long left = hi - lo;
+    sg.d1 = (long long)sg.d0 + left < dm.D ? sg.d0 + (int)left : dm.D;
+    sg.gs = item % dm.splits;
+    sg.tile = (item / dm.splits) % dm.tiles;
+    sg.b = item / (dm.splits * dm.tiles);
+    lo += sg.d1 - sg.d0;
+    return true;
 }
 
 struct Tap4 {
@@ -209,21 +206,20 @@ template <int GS, int N, int TW, bool FUSED>
 __device__ __forceinline__ bool tile_setup(const float *__restrict__ src, const float *__restrict__ K,
                                            const float *__restrict__ invK, const float *__restrict__ pose,
                                            const float *__restrict__ hyp, const float *__restrict__ prior,
-                                           const float *__restrict__ ztrans, const CvDims &dm, float4 *win, int *bb,
-                                           float *itv, Walk<FUSED> &wk, int &b, int &gbase, int &p, int &d0, int &d1,
-                                           int &ox, int &oy) {
+                                           const float *__restrict__ ztrans, const CvDims &dm, const Seg &sg, float4 *win,
+                                           int *bb, float *itv, Walk<FUSED> &wk, int &b, int &gbase, int &p, int &d0,
+                                           int &d1, int &ox, int &oy) {
     constexpr int CPW = GS * N, QPP = CPW / 4;
     using T = Tile<TW, CPW>;
     const int tid = threadIdx.x;
-    b = blockIdx.z / dm.dsplit;
-    const int ds = blockIdx.z % dm.dsplit;
-    gbase = blockIdx.y * GS;
-    const int tx0 = (blockIdx.x % dm.tiles_x) * TW, ty0 = (blockIdx.x / dm.tiles_x) * T::TH;
+    b = sg.b;
+    gbase = sg.gs * GS;
+    const int tx0 = (sg.tile % dm.tiles_x) * TW, ty0 = (sg.tile / dm.tiles_x) * T::TH;
     const int x = tx0 + tid % TW, y = ty0 + tid / TW;
     const bool valid = x < dm.w && y < dm.h;
     p = y * dm.w + x;
-    d0 = ds * dm.dper;
-    d1 = min(dm.D, d0 + dm.dper);
+    d0 = sg.d0;
+    d1 = sg.d1;
     const size_t hw = (size_t)dm.h * dm.w;
     wk.cam = md_load_cam(K + b * 16, invK + b * 16, pose + b * 16);
     md_ray(wk.cam, (float)x, (float)y, wk.r0, wk.r1, wk.r2);
@@ -292,7 +288,7 @@ __device__ __forceinline__ bool tile_setup(const float *__restrict__ src, const 
     return valid;
 }
 
-template <int GS, int N, int TW, bool FUSED, bool WIDE>
+template <int GS, int N, int TW, bool FUSED>
 __global__ __launch_bounds__(256) void costvol_fwd_kernel(const float *__restrict__ ref, const float *__restrict__ src,
                                                           const float *__restrict__ K, const float *__restrict__ invK,
                                                           const float *__restrict__ pose, const float *__restrict__ hyp,
@@ -304,38 +300,38 @@ __global__ __launch_bounds__(256) void costvol_fwd_kernel(const float *__restric
     __shared__ float4 win[T::WP * QPP];
     __shared__ float itv[ITV_MAX];
     __shared__ int bb[16];
+    const long long total = (long long)dm.items * dm.D;
+    long long lo = total * blockIdx.x / gridDim.x;
+    const long long hi = total * (blockIdx.x + 1) / gridDim.x;
+    Seg sg;
+    while (next_segment(dm, lo, hi, sg)) {
     Walk<FUSED> wk;
     int b, gbase, p, d0, d1, ox, oy;
-    if (!tile_setup<GS, N, TW, FUSED>(src, K, invK, pose, hyp, prior, ztrans, dm, win, bb, itv, wk, b, gbase, p, d0, d1,
-                                      ox, oy))
-        return;
-
+    const bool valid = tile_setup<GS, N, TW, FUSED>(src, K, invK, pose, hyp, prior, ztrans, dm, sg, win, bb, itv, wk, b,
+                                                    gbase, p, d0, d1, ox, oy);
     const size_t hw = (size_t)dm.h * dm.w;
     const float *srcb = src + (size_t)b * dm.C * hw;
-    vecf<CPW> rf;  // ref features with the 1/N of the group mean folded in
+    vecf<CPW> rf = 0.f;  // ref features with the 1/N of the group mean folded in
+    if (valid) {
 #pragma unroll
-    for (int k = 0; k < CPW; ++k)
-        rf[k] = ref[((size_t)b * dm.C + slot_channel<N>(k, dm.G, gbase)) * hw + p] * (1.f / (float)N);
-
-    float *outp = out + (size_t)b * dm.sb + (size_t)gbase * dm.sg + (size_t)d0 * dm.sd + p;
-    // wide stores: lane 4i+m writes group m of each 4-group batch at pixels 4i..4i+3 (p is lane 4i+m's own pixel)
-    const long long wide_off = (long long)(threadIdx.x & 3) * dm.sg - (long long)(threadIdx.x & 3);
-    float dnext = wk.hypothesis(itv, d0);
-    for (int d = d0; d < d1; ++d) {
+        for (int k = 0; k < CPW; ++k)
+            rf[k] = ref[((size_t)b * dm.C + slot_channel<N>(k, dm.G, gbase)) * hw + p] * (1.f / (float)N);
+    }
+    float *outp = out + (size_t)b * dm.sb + (size_t)gbase * dm.sg + (size_t)d0 * dm.sd + (size_t)p * dm.sp;
+    float dnext = valid ? wk.hypothesis(itv, d0) : 1.f;
+    for (int d = d0; valid && d < d1; ++d) {
         const float dep = dnext;
         if (d + 1 < d1) dnext = wk.hypothesis(itv, d + 1);
         const Tap4 t = wk.tap_at(dep);
         const int lx = t.x0 - ox, ly = t.y0 - oy;
         const bool in_win = (unsigned)lx < (unsigned)(T::WW - 1) && (unsigned)ly < (unsigned)(T::WH - 1);
-        // the quad transpose of the wide-store path needs every lane of the wave on the fast path
-        if (WIDE ? __all(in_win) : in_win) {
+        if (in_win) {
             // channels go through in 16-byte quads (one LDS plane per quad: neighbouring lanes read neighbouring
             // 16-byte slots, conflict free, and every tap address is the same base + an immediate offset);
             // a group's output is emitted as soon as its N channels are in
             const float4 *wp = win + ly * T::WW + lx;
             const v2f w00 = t.w00, w01 = t.w01, w10 = t.w10, w11 = t.w11;  // broadcast pairs -> v_pk_fma_f32
             float acc = 0.f;
-            float o4[4];
 #pragma unroll
             for (int q = 0; q < QPP; ++q) {
                 const float4 a00 = wp[q * T::WP], a01 = wp[q * T::WP + 1];
@@ -351,18 +347,7 @@ __global__ __launch_bounds__(256) void costvol_fwd_kernel(const float *__restric
                     acc += S4[e];
                     if (k % N == N - 1) {
                         const int j = k / N;  // group done
-                        if (WIDE) {
-                            o4[j % 4] = acc;
-                            if (j % 4 == 3) {
-                                // 4x4 transpose across each lane quad: lane 4i+m ends up with group (j-3+m) at
-                                // pixels 4i..4i+3, one 16-byte store per lane instead of four 4-byte ones
-                                quad_transpose(o4);
-                                float *dst = outp + (size_t)(j - 3) * dm.sg + wide_off;
-                                *reinterpret_cast<float4 *>(dst) = make_float4(o4[0], o4[1], o4[2], o4[3]);
-                            }
-                        } else {
-                            outp[(size_t)j * dm.sg] = acc;
-                        }
+                        outp[(size_t)j * dm.sg] = acc;
                         acc = 0.f;
                     }
                 }
@@ -378,6 +363,122 @@ __global__ __launch_bounds__(256) void costvol_fwd_kernel(const float *__restric
             }
         }
         outp += dm.sd;
+    }
+    __syncthreads();  // the window is restaged by the next segment
+    }
+}
+
+// Channels-last volume (B,D,h,w,G): the layout MIOpen's fast 3-D convolutions consume.  A pixel's groups are
+// contiguous in memory, so a lane owning a pixel would store 16-byte pieces at a 4*G-byte stride: every store
+// instruction would touch 64 different 64-byte segments (measured 107 us vs 60 us planar).  Instead each wave
+// transposes its (64 pixels x GS groups) result through a private, padded LDS tile and writes it back in memory
+// order: lane l of store k writes the 16 bytes at linear position (k*64 + l) of the wave's pixel-major block --
+// consecutive lanes, consecutive addresses, 1 KB per instruction.
+template <int GS, int N, int TW, bool FUSED>
+__global__ __launch_bounds__(256) void costvol_fwd_nhwc_kernel(const float *__restrict__ ref, const float *__restrict__ src,
+                                                               const float *__restrict__ K, const float *__restrict__ invK,
+                                                               const float *__restrict__ pose, const float *__restrict__ hyp,
+                                                               const float *__restrict__ prior,
+                                                               const float *__restrict__ ztrans, float *__restrict__ out,
+                                                               const CvDims dm) {
+    constexpr int CPW = GS * N, QPP = CPW / 4, NCH = GS / 4;  // NCH 16-byte chunks of groups per pixel
+    // transpose tile: [64 pixels][NCH chunks] of float4, chunk index XOR-swizzled with the pixel so that both the
+    // per-pixel writes (8-lane groups, 64-byte pitch) and the memory-order reads are bank-conflict free without
+    // padding (padding would push the workgroup past half a CU's LDS)
+    constexpr int PADW = NCH;
+    constexpr int SWZ = NCH - 1;  // NCH is 1, 2 or 4
+    static_assert(GS % 4 == 0, "channels-last stores need a multiple of 4 groups per workgroup");
+    using T = Tile<TW, CPW>;
+    __shared__ float4 win[T::WP * QPP];
+    __shared__ float4 stage[4 * 64 * PADW];
+    __shared__ float itv[ITV_MAX];
+    __shared__ int bb[16];
+    const long long total = (long long)dm.items * dm.D;
+    long long lo = total * blockIdx.x / gridDim.x;
+    const long long hi = total * (blockIdx.x + 1) / gridDim.x;
+    Seg sg;
+    while (next_segment(dm, lo, hi, sg)) {
+    Walk<FUSED> wk;
+    int b, gbase, p, d0, d1, ox, oy;
+    const bool valid = tile_setup<GS, N, TW, FUSED>(src, K, invK, pose, hyp, prior, ztrans, dm, sg, win, bb, itv, wk, b,
+                                                    gbase, p, d0, d1, ox, oy);
+    const size_t hw = (size_t)dm.h * dm.w;
+    const float *srcb = src + (size_t)b * dm.C * hw;
+    vecf<CPW> rf = 0.f;  // ref features with the 1/N of the group mean folded in
+    if (valid) {
+#pragma unroll
+        for (int k = 0; k < CPW; ++k)
+            rf[k] = ref[((size_t)b * dm.C + slot_channel<N>(k, dm.G, gbase)) * hw + p] * (1.f / (float)N);
+    }
+    // write-back roles: store k of this lane covers 16-byte piece (k*64 + lane) of the wave's block
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float4 *my_stage = stage + wave * 64 * PADW;
+    constexpr int RPW = 64 / TW > 0 ? 64 / TW : 1;  // tile rows per wave (TW = 32: 2, TW = 64: 1)
+    const int tx0 = (sg.tile % dm.tiles_x) * TW, ty0 = (sg.tile / dm.tiles_x) * T::TH + wave * RPW;
+    long long soff[NCH];  // global offsets (floats) of this lane's NCH stores; < 0: nothing to store
+    int sidx[NCH];        // where the piece sits in the padded transpose tile
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const int L = k * 64 + lane, pw = L / NCH, ch = L % NCH;  // pixel-in-wave, chunk
+        const int px = tx0 + pw % TW, py = ty0 + pw / TW;
+        sidx[k] = pw * PADW + (ch ^ ((pw >> 1) & SWZ));
+        soff[k] = (px < dm.w && py < dm.h)
+                      ? (long long)b * dm.sb + (long long)d0 * dm.sd + ((long long)py * dm.w + px) * dm.sp + gbase + ch * 4
+                      : -1;
+    }
+    float dnext = valid ? wk.hypothesis(itv, d0) : 1.f;
+    for (int d = d0; d < d1; ++d) {
+        float og[GS];
+        if (valid) {
+            const float dep = dnext;
+            if (d + 1 < d1) dnext = wk.hypothesis(itv, d + 1);
+            const Tap4 t = wk.tap_at(dep);
+            const int lx = t.x0 - ox, ly = t.y0 - oy;
+            if ((unsigned)lx < (unsigned)(T::WW - 1) && (unsigned)ly < (unsigned)(T::WH - 1)) {
+                const float4 *wp = win + ly * T::WW + lx;
+                const v2f w00 = t.w00, w01 = t.w01, w10 = t.w10, w11 = t.w11;
+                float acc = 0.f;
+#pragma unroll
+                for (int q = 0; q < QPP; ++q) {
+                    const float4 a00 = wp[q * T::WP], a01 = wp[q * T::WP + 1];
+                    const float4 a10 = wp[q * T::WP + T::WW], a11 = wp[q * T::WP + T::WW + 1];
+                    const v2f lo = v2f{a00.x, a00.y} * w00 + v2f{a01.x, a01.y} * w01 + v2f{a10.x, a10.y} * w10 + v2f{a11.x, a11.y} * w11;
+                    const v2f hi = v2f{a00.z, a00.w} * w00 + v2f{a01.z, a01.w} * w01 + v2f{a10.z, a10.w} * w10 + v2f{a11.z, a11.w} * w11;
+                    const v2f plo = lo * v2f{rf[q * 4 + 0], rf[q * 4 + 1]}, phi = hi * v2f{rf[q * 4 + 2], rf[q * 4 + 3]};
+                    const float S4[4] = {plo.x, plo.y, phi.x, phi.y};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int k = q * 4 + e;
+                        acc += S4[e];
+                        if (k % N == N - 1) { og[k / N] = acc; acc = 0.f; }
+                    }
+                }
+            } else {
+                const vecf<CPW> S = sample_slow<CPW, N>(srcb, dm.h, dm.w, dm.G, gbase, t.x0, t.y0, t.w00, t.w01, t.w10, t.w11);
+#pragma unroll
+                for (int j = 0; j < GS; ++j) {
+                    float acc = 0.f;
+#pragma unroll
+                    for (int i = 0; i < N; ++i) acc += S[j * N + i] * rf[j * N + i];
+                    og[j] = acc;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < GS; ++j) og[j] = 0.f;
+        }
+        // transpose through the wave's LDS tile (LDS operations of one wave execute in order: no barrier)
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) my_stage[lane * PADW + (c ^ ((lane >> 1) & SWZ))] = make_float4(og[4 * c], og[4 * c + 1], og[4 * c + 2], og[4 * c + 3]);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const float4 v = my_stage[sidx[k]];
+            if (soff[k] >= 0) *reinterpret_cast<float4 *>(out + soff[k] + (long long)(d - d0) * dm.sd) = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();  // the window is restaged by the next segment
     }
 }
 
@@ -396,10 +497,15 @@ __global__ __launch_bounds__(256) void costvol_bwd_kernel(const float *__restric
     __shared__ float itv[ITV_MAX];
     __shared__ int bb[16];
     const int tid = threadIdx.x;
+    const long long total = (long long)dm.items * dm.D;
+    long long lo = total * blockIdx.x / gridDim.x;
+    const long long hi = total * (blockIdx.x + 1) / gridDim.x;
+    Seg sg;
+    while (next_segment(dm, lo, hi, sg)) {
     for (int i = tid; i < CPW * WP; i += 256) gw[i] = 0.f;
     Walk<FUSED> wk;
     int b, gbase, p, d0, d1, ox, oy;
-    const bool valid = tile_setup<GS, N, TW, FUSED>(src, K, invK, pose, hyp, prior, ztrans, dm, win, bb, itv, wk, b,
+    const bool valid = tile_setup<GS, N, TW, FUSED>(src, K, invK, pose, hyp, prior, ztrans, dm, sg, win, bb, itv, wk, b,
                                                     gbase, p, d0, d1, ox, oy);  // its barriers publish the zeroed gw
     const size_t hw = (size_t)dm.h * dm.w;
     const float *srcb = src + (size_t)b * dm.C * hw;
@@ -411,7 +517,7 @@ __global__ __launch_bounds__(256) void costvol_bwd_kernel(const float *__restric
             rf[k] = ref[((size_t)b * dm.C + slot_channel<N>(k, dm.G, gbase)) * hw + p] * (1.f / (float)N);
         vecf<CPW> a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;  // pending d_src quad at cell (bx, by)
         int bx = INT_MIN, by = INT_MIN;
-        const float *gp = gout + (size_t)b * dm.sb + (size_t)gbase * dm.sg + (size_t)d0 * dm.sd + p;
+        const float *gp = gout + (size_t)b * dm.sb + (size_t)gbase * dm.sg + (size_t)d0 * dm.sd + (size_t)p * dm.sp;
         float dnext = wk.hypothesis(itv, d0);
         for (int d = d0; d <= d1; ++d) {
             Tap4 t;
@@ -460,7 +566,7 @@ __global__ __launch_bounds__(256) void costvol_bwd_kernel(const float *__restric
         for (int k = 0; k < CPW; ++k) {
             float *o = drp + (size_t)slot_channel<N>(k, dm.G, gbase) * hw;
             const float v = dref[k] * (1.f / (float)N);  // the group mean's 1/N (rf carries it on the d_src side)
-            if (dm.dsplit == 1) *o = v;
+            if (d0 == 0 && d1 == dm.D) *o = v;  // this segment is the pixel's only contributor
             else unsafeAtomicAdd(o, v);
         }
     }
@@ -473,6 +579,8 @@ __global__ __launch_bounds__(256) void costvol_bwd_kernel(const float *__restric
         const int sx = ox + cell % T::WW, sy = oy + cell / T::WW;
         if (sx >= 0 && sx < dm.w && sy >= 0 && sy < dm.h)
             unsafeAtomicAdd(dsrcb + (size_t)slot_channel<N>(k, dm.G, gbase) * hw + (size_t)sy * dm.w + sx, v);
+    }
+    __syncthreads();  // gw / win are reused by the next segment
     }
 }
 
@@ -497,7 +605,9 @@ int launch(const CvPtrs &q, CvDims dm, hipStream_t stream) {
     // channels per workgroup: coordinates are computed once per (pixel, hypothesis) for all of them, but LDS per
     // workgroup grows with it; 16 measured best for the forward at 48x160 (8: 68 us, 16: 61 us, 32: 70 us).  The
     // backward keeps 4 x CPW scatter accumulators in registers, so it carries 8.
-    int cpw_target = env_int(BWD ? "MD_COSTVOL_CPW_BWD" : "MD_COSTVOL_CPW", BWD ? 8 : 16);
+    // channels-last output: all of a pixel's groups must come from one workgroup to write whole 64-byte lines
+    const bool cl_out = !BWD && dm.sg == 1;
+    int cpw_target = env_int(BWD ? "MD_COSTVOL_CPW_BWD" : "MD_COSTVOL_CPW", BWD ? 8 : (cl_out ? 32 : 16));
     int GS = 0;
     for (int cpw = cpw_target; cpw >= 4 && !GS; cpw /= 2)
         if (cpw % N == 0 && dm.G % (cpw / N) == 0) GS = cpw / N;
@@ -515,42 +625,52 @@ int launch(const CvPtrs &q, CvDims dm, hipStream_t stream) {
     dm.dbg = env_int("MD_COSTVOL_DEBUG", 0);
     const int tiles = dm.tiles_x * md_cdiv(dm.h, TH);
     const int splits = dm.G / GS;
-    // D slices: every workgroup should be resident at once (no second, partially filled round), as close to
-    // the chip's slot count as the slicing allows.  Slots = 256 CUs x workgroups per CU by LDS (and 8 by waves).
-    int dsplit = env_int(BWD ? "MD_COSTVOL_DSPLIT_BWD" : "MD_COSTVOL_DSPLIT", 0);
-    if (dsplit <= 0) {
+    // Grid: every work item (sample, tile, channel split) is cut into `dsplit` equal hypothesis slices, one
+    // workgroup each, with dsplit the largest divisor of D that keeps all workgroups resident at once (slots =
+    // 256 CUs x workgroups per CU by LDS, <= 8 by waves) and leaves >= 8 hypotheses per slice.  Measured at
+    // B=6, 48x160, D=96: slices that straddle two items (a perfectly balanced linear split) cost more in window
+    // re-staging than the balance wins (72 vs 60 us), so slices never cross items unless MD_COSTVOL_NWG forces it.
+    dm.tiles = tiles;
+    dm.splits = splits;
+    dm.items = dm.B * tiles * splits;
+    const long long total = (long long)dm.items * dm.D;
+    long long nwg = env_int(BWD ? "MD_COSTVOL_NWG_BWD" : "MD_COSTVOL_NWG", 0);
+    if (nwg <= 0) {
         const int wp = (TW + (CPW >= 32 ? 8 : 16)) * (TH + (CPW >= 32 ? 4 : 8));
-        const long long lds = (long long)wp * CPW * 4 * (BWD ? 2 : 1) + ITV_MAX * 4 + 64;
+        const long long lds = (long long)wp * CPW * 4 * (BWD ? 2 : 1) + ITV_MAX * 4 + 64 +
+                              ((!BWD && dm.sg == 1) ? 4 * 64 * (GS / 4) * 16 : 0);
         long long per_cu = (160 * 1024) / lds;
         if (per_cu > 8) per_cu = 8;
         if (per_cu < 1) per_cu = 1;
-        const long long slots = 256 * per_cu, wgs = (long long)tiles * splits * dm.B;
-        dsplit = (int)(slots / wgs);
-        const int cap = dm.D / 8 > 0 ? dm.D / 8 : 1;  // at least 8 hypotheses per slice: staging must amortise
-        if (dsplit > cap) dsplit = cap;
+        const long long slots = 256 * per_cu;
+        int dsplit = env_int(BWD ? "MD_COSTVOL_DSPLIT_BWD" : "MD_COSTVOL_DSPLIT", 0);
+        if (dsplit <= 0) {
+            dsplit = 1;
+            for (int c = 2; c <= dm.D / 8; ++c)
+                if (dm.D % c == 0 && (long long)dm.items * c <= slots) dsplit = c;
+        }
+        while (dm.D % dsplit != 0) --dsplit;
+        nwg = (long long)dm.items * dsplit;
     }
-    if (dsplit < md_cdiv(dm.D, ITV_MAX)) dsplit = md_cdiv(dm.D, ITV_MAX);  // slices fit the LDS interval table
-    if (dsplit > dm.D) dsplit = dm.D;
-    if (dsplit < 1) dsplit = 1;
-    dm.dper = md_cdiv(dm.D, dsplit);
-    dm.dsplit = md_cdiv(dm.D, dm.dper);
-    const dim3 grid(tiles, splits, dm.B * dm.dsplit), block(256);
-    // 16-byte stores need 4-pixel lane quads inside one row and 16-byte aligned planes
-    const bool wide = !BWD && env_int("MD_COSTVOL_WIDE", 0) && dm.w % 4 == 0 && dm.sb % 4 == 0 && dm.sd % 4 == 0 &&
-                      dm.sg % 4 == 0 && ((uintptr_t)q.out % 16) == 0;
-    (void)wide;
+    if (nwg > total) nwg = total;
+    if (nwg * ITV_MAX < total) nwg = (total + ITV_MAX - 1) / ITV_MAX;  // a share fits the interval table
+    const dim3 grid((unsigned)nwg), block(256);
+    // channels-last volume (sg == 1): 16-byte stores of 4 consecutive groups, given 16-byte alignment
+    const bool nhwc = !BWD && dm.sg == 1 && dm.G % 4 == 0 && dm.sb % 4 == 0 && dm.sd % 4 == 0 && dm.sp % 4 == 0 &&
+                      ((uintptr_t)q.out % 16) == 0;
+    (void)nhwc;
 
 #define MD_CV_LAUNCH(GS_, N_, TW_, F_)                                                                                \
     do {                                                                                                              \
         if (BWD)                                                                                                      \
             hipLaunchKernelGGL((costvol_bwd_kernel<GS_, N_, TW_, F_>), grid, block, 0, stream, q.gout, q.ref, q.src,  \
                                q.K, q.invK, q.pose, q.hyp, q.prior, q.ztrans, q.d_ref, q.d_src, dm);                  \
-        else if (wide && (GS_) % 4 == 0)                                                                              \
-            hipLaunchKernelGGL((costvol_fwd_kernel<GS_, N_, TW_, F_, ((GS_) % 4 == 0)>), grid, block, 0, stream,      \
-                               q.ref, q.src, q.K, q.invK, q.pose, q.hyp, q.prior, q.ztrans, q.out, dm);               \
+        else if (nhwc && (GS_) % 4 == 0)                                                                              \
+            hipLaunchKernelGGL((costvol_fwd_nhwc_kernel<((GS_) % 4 == 0 ? (GS_) : 4), N_, TW_, F_>), grid, block, 0,  \
+                               stream, q.ref, q.src, q.K, q.invK, q.pose, q.hyp, q.prior, q.ztrans, q.out, dm);       \
         else                                                                                                          \
-            hipLaunchKernelGGL((costvol_fwd_kernel<GS_, N_, TW_, F_, false>), grid, block, 0, stream, q.ref, q.src,   \
-                               q.K, q.invK, q.pose, q.hyp, q.prior, q.ztrans, q.out, dm);                             \
+            hipLaunchKernelGGL((costvol_fwd_kernel<GS_, N_, TW_, F_>), grid, block, 0, stream, q.ref, q.src, q.K,     \
+                               q.invK, q.pose, q.hyp, q.prior, q.ztrans, q.out, dm);                                  \
     } while (0)
 #define MD_CV_F(GS_, N_, TW_)                        \
     do {                                             \
@@ -611,7 +731,8 @@ int check_common(const char *fn, const void *ref, const void *src, const void *K
 extern "C" int md_costvol_fwd(const float *ref, const float *src, const float *K, const float *invK,
                               const float *pose, const float *hyp, const float *prior, const float *ztrans,
                               float scale_fac, int sched_type, int B, int C, int G, int h, int w, int D, float *out,
-                              long long out_sb, long long out_sd, long long out_sg, md_stream_t stream) {
+                              long long out_sb, long long out_sd, long long out_sg, long long out_sp,
+                              md_stream_t stream) {
     int rc = check_common("md_costvol_fwd", ref, src, K, invK, pose, hyp, prior, sched_type, B, C, G, h, w, D);
     if (rc) return rc;
     MD_REQUIRE(out, "md_costvol_fwd: null output");
@@ -621,11 +742,12 @@ extern "C" int md_costvol_fwd(const float *ref, const float *src, const float *K
     CvDims dm{};
     dm.scale_fac = scale_fac; dm.sched_type = sched_type;
     dm.B = B; dm.C = C; dm.G = G; dm.h = h; dm.w = w; dm.D = D;
-    dm.sb = out_sb; dm.sd = out_sd; dm.sg = out_sg;
+    dm.sb = out_sb; dm.sd = out_sd; dm.sg = out_sg; dm.sp = out_sp;
     return launch<false>(q, dm, (hipStream_t)stream);
 }
 
-extern "C" int md_costvol_bwd(const float *gout, long long g_sb, long long g_sd, long long g_sg, const float *ref,
+extern "C" int md_costvol_bwd(const float *gout, long long g_sb, long long g_sd, long long g_sg, long long g_sp,
+                              const float *ref,
                               const float *src, const float *K, const float *invK, const float *pose,
                               const float *hyp, const float *prior, const float *ztrans, float scale_fac,
                               int sched_type, int B, int C, int G, int h, int w, int D, float *d_ref, float *d_src,
@@ -639,7 +761,7 @@ extern "C" int md_costvol_bwd(const float *gout, long long g_sb, long long g_sd,
     CvDims dm{};
     dm.scale_fac = scale_fac; dm.sched_type = sched_type;
     dm.B = B; dm.C = C; dm.G = G; dm.h = h; dm.w = w; dm.D = D;
-    dm.sb = g_sb; dm.sd = g_sd; dm.sg = g_sg;
+    dm.sb = g_sb; dm.sd = g_sd; dm.sg = g_sg; dm.sp = g_sp;
     const size_t bytes = sizeof(float) * (size_t)B * C * h * w;
     MD_CHECK_HIP(hipMemsetAsync(d_src, 0, bytes, (hipStream_t)stream));
     MD_CHECK_HIP(hipMemsetAsync(d_ref, 0, bytes, (hipStream_t)stream));

@@ -16,7 +16,7 @@ struct FuseArgs {
     const float *gout;
     float *out, *weights;
     int N, B, D, G, hw;
-    long long sb, sd, sg;
+    long long sb, sd, sg, sp;
 };
 
 // online max / sum-exp over the G group means of one frame at one pixel
@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void fuse_fwd_kernel(FuseArgs a) {
         wf[f] = 0.f;
         if (f < a.N) {
             float M, s; int am;
-            frame_weight(a.vol[f] + (size_t)b * a.sb + p, a, M, s, am);
+            frame_weight(a.vol[f] + (size_t)b * a.sb + (size_t)p * a.sp, a, M, s, am);
             wf[f] = 1.f / s;
             wsum += wf[f];
             if (a.weights) a.weights[((size_t)f * a.B + b) * a.hw + p] = wf[f];
@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void fuse_fwd_kernel(FuseArgs a) {
     }
     for (int d = 0; d < a.D; ++d)
         for (int g = 0; g < a.G; ++g) {
-            const size_t o = (size_t)b * a.sb + (size_t)d * a.sd + (size_t)g * a.sg + p;
+            const size_t o = (size_t)b * a.sb + (size_t)d * a.sd + (size_t)g * a.sg + (size_t)p * a.sp;
             float acc = 0.f;
 #pragma unroll
             for (int f = 0; f < MAXF; ++f)
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void fuse_bwd_kernel(FuseArgs a) {
     for (int f = 0; f < MAXF; ++f) {
         wf[f] = 0.f; dw[f] = 0.f; Mf[f] = 0.f; sf[f] = 1.f; am[f] = 0;
         if (f < a.N) {
-            frame_weight(a.vol[f] + (size_t)b * a.sb + p, a, Mf[f], sf[f], am[f]);
+            frame_weight(a.vol[f] + (size_t)b * a.sb + (size_t)p * a.sp, a, Mf[f], sf[f], am[f]);
             wf[f] = 1.f / sf[f];
             wsum += wf[f];
         }
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void fuse_bwd_kernel(FuseArgs a) {
     // dL/dw_f = sum_{d,g} gout * (vol_f - cor) / wsum
     for (int d = 0; d < a.D; ++d)
         for (int g = 0; g < a.G; ++g) {
-            const size_t o = (size_t)b * a.sb + (size_t)d * a.sd + (size_t)g * a.sg + p;
+            const size_t o = (size_t)b * a.sb + (size_t)d * a.sd + (size_t)g * a.sg + (size_t)p * a.sp;
             float v[MAXF], acc = 0.f;
 #pragma unroll
             for (int f = 0; f < MAXF; ++f) {
@@ -88,8 +88,8 @@ __global__ __launch_bounds__(256) void fuse_bwd_kernel(FuseArgs a) {
 #pragma unroll
     for (int f = 0; f < MAXF; ++f) {
         if (f >= a.N) continue;
-        const float *v = a.vol[f] + (size_t)b * a.sb + p;
-        float *dv = a.dvol[f] + (size_t)b * a.sb + p;
+        const float *v = a.vol[f] + (size_t)b * a.sb + (size_t)p * a.sp;
+        float *dv = a.dvol[f] + (size_t)b * a.sb + (size_t)p * a.sp;
         const float pstar = wf[f];  // softmax probability of the arg-max group
         for (int g = 0; g < a.G; ++g) {
             float acc = 0.f;
@@ -99,29 +99,29 @@ __global__ __launch_bounds__(256) void fuse_bwd_kernel(FuseArgs a) {
             const float add = dw[f] * dm / (float)a.D;
             for (int d = 0; d < a.D; ++d) {
                 const size_t o = (size_t)d * a.sd + (size_t)g * a.sg;
-                dv[o] = a.gout[(size_t)b * a.sb + o + p] * wf[f] / wsum + add;
+                dv[o] = a.gout[(size_t)b * a.sb + o + (size_t)p * a.sp] * wf[f] / wsum + add;
             }
         }
     }
 }
 
 int fill(FuseArgs &a, const char *fn, const float *const *vols, int N, int B, int D, int G, int hw, long long sb,
-         long long sd, long long sg) {
+         long long sd, long long sg, long long sp) {
     MD_REQUIRE(vols, "%s: null volume list", fn);
     MD_REQUIRE(N >= 1 && N <= MAXF, "%s: %d lookup frames unsupported (1..%d)", fn, N, MAXF);
     MD_REQUIRE(B > 0 && B <= 65535 && D > 0 && G > 0 && hw > 0, "%s: bad dims", fn);
     for (int f = 0; f < MAXF; ++f) a.vol[f] = f < N ? vols[f] : nullptr;
     for (int f = 0; f < N; ++f) MD_REQUIRE(vols[f], "%s: null volume %d", fn, f);
-    a.N = N; a.B = B; a.D = D; a.G = G; a.hw = hw; a.sb = sb; a.sd = sd; a.sg = sg;
+    a.N = N; a.B = B; a.D = D; a.G = G; a.hw = hw; a.sb = sb; a.sd = sd; a.sg = sg; a.sp = sp;
     return MD_OK;
 }
 
 }  // namespace
 
 extern "C" int md_fuse_fwd(const float *const *vols, int N, int B, int D, int G, int hw, long long sb, long long sd,
-                           long long sg, float *out, float *weights, md_stream_t stream) {
+                           long long sg, long long sp, float *out, float *weights, md_stream_t stream) {
     FuseArgs a{};
-    int rc = fill(a, "md_fuse_fwd", vols, N, B, D, G, hw, sb, sd, sg);
+    int rc = fill(a, "md_fuse_fwd", vols, N, B, D, G, hw, sb, sd, sg, sp);
     if (rc) return rc;
     MD_REQUIRE(out, "md_fuse_fwd: null output");
     a.out = out; a.weights = weights;
@@ -131,9 +131,10 @@ extern "C" int md_fuse_fwd(const float *const *vols, int N, int B, int D, int G,
 }
 
 extern "C" int md_fuse_bwd(const float *gout, const float *const *vols, int N, int B, int D, int G, int hw,
-                           long long sb, long long sd, long long sg, float *const *d_vols, md_stream_t stream) {
+                           long long sb, long long sd, long long sg, long long sp, float *const *d_vols,
+                           md_stream_t stream) {
     FuseArgs a{};
-    int rc = fill(a, "md_fuse_bwd", vols, N, B, D, G, hw, sb, sd, sg);
+    int rc = fill(a, "md_fuse_bwd", vols, N, B, D, G, hw, sb, sd, sg, sp);
     if (rc) return rc;
     MD_REQUIRE(gout && d_vols, "md_fuse_bwd: null gradient");
     for (int f = 0; f < N; ++f) {

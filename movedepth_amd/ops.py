@@ -12,6 +12,36 @@ from . import _lib
 
 _TYPES = {"inverse": 0, "linear": 1, "log": 2}
 
+# Optional per-launch timing with HIP events on the stream the kernels are launched on (torch's current
+# stream).  bench.py switches it on for the roofline figure; off (None) it costs nothing.
+KERNEL_EVENTS = None  # or dict: entry-point name -> list of (start_event, end_event)
+
+
+def enable_kernel_timing(names):
+    global KERNEL_EVENTS
+    KERNEL_EVENTS = {n: [] for n in names}
+
+
+def kernel_times_us():
+    """Average duration per timed entry point (call after torch.cuda.synchronize())."""
+    out = {}
+    for n, evs in (KERNEL_EVENTS or {}).items():
+        if evs:
+            ts = [a.elapsed_time(b) * 1e3 for a, b in evs]
+            out[n] = {"avg_us": sum(ts) / len(ts), "min_us": min(ts), "launches": len(ts)}
+    return out
+
+
+def _timed_call(name, *args):
+    if KERNEL_EVENTS is not None and name in KERNEL_EVENTS:
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        _lib.call(name, *args)
+        b.record()
+        KERNEL_EVENTS[name].append((a, b))
+    else:
+        _lib.call(name, *args)
+
 
 def _p(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
@@ -57,9 +87,45 @@ def schedule_depth_range(prior_depth, ndepth, scale_fac, z_trans=None, type="inv
 
 
 # --------------------------------------------------------------------------- cost volume
+def _vol_alloc(layout, B, D, G, h, w, device):
+    """Storage + (sb, sd, sg, sp) strides + the logical (B,D,G,h,w) view for a grouped volume.
+       'bdg'  : (B,D,G,h,w) contiguous -- the reference's layout;
+       'bgd'  : (B,G,D,h,w) contiguous -- what reg3d's permute asks for (NCDHW);
+       'ndhwc': (B,D,h,w,G) contiguous -- channels_last_3d for reg3d, the layout MIOpen's fast 3-D convs take."""
+    if layout == "bgd":
+        store = torch.empty(B, G, D, h, w, device=device, dtype=torch.float32)
+        return store, (store.stride(0), store.stride(2), store.stride(1), 1), store.permute(0, 2, 1, 3, 4)
+    if layout == "ndhwc":
+        store = torch.empty(B, D, h, w, G, device=device, dtype=torch.float32)
+        return store, (store.stride(0), store.stride(1), 1, G), store.permute(0, 1, 4, 2, 3)
+    if layout == "bdg":
+        store = torch.empty(B, D, G, h, w, device=device, dtype=torch.float32)
+        return store, (store.stride(0), store.stride(1), store.stride(2), 1), store
+    raise ValueError("unknown volume layout %r" % (layout,))
+
+
+def _vol_as_layout(t, layout):
+    """Logical (B,D,G,h,w) tensor -> contiguous storage in `layout` (no copy when it already is) + strides."""
+    if layout == "bgd":
+        g = t.permute(0, 2, 1, 3, 4).contiguous()
+        return g, (g.stride(0), g.stride(2), g.stride(1), 1)
+    if layout == "ndhwc":
+        g = t.permute(0, 1, 3, 4, 2).contiguous()
+        return g, (g.stride(0), g.stride(1), 1, g.shape[4])
+    g = t.contiguous()
+    return g, (g.stride(0), g.stride(1), g.stride(2), 1)
+
+
+def _vol_logical(store, layout):
+    if layout == "bgd":
+        return store.permute(0, 2, 1, 3, 4)
+    if layout == "ndhwc":
+        return store.permute(0, 1, 4, 2, 3)
+    return store
+
+
 class _CostVolume(torch.autograd.Function):
-    """Grouped plane-sweep volume.  Returns a tensor of logical shape (B,D,G,h,w); with layout='bgd' its storage
-    is (B,G,D,h,w)-contiguous, i.e. `.permute(0,2,1,3,4)` (what reg3d does first) is contiguous."""
+    """Grouped plane-sweep volume; returns a tensor of logical shape (B,D,G,h,w) over `layout` storage."""
 
     @staticmethod
     def forward(ctx, ref, src, K, invK, pose, hyp, prior, ztrans, scale_fac, sched_type, G, D, layout):
@@ -67,16 +133,9 @@ class _CostVolume(torch.autograd.Function):
         K, invK, pose = _prep(K, "K"), _prep(invK, "invK"), _prep(pose, "pose")
         hyp, prior, ztrans = _prep(hyp, "depth_priors"), _prep(prior, "prior"), _prep(ztrans, "z_trans")
         B, C, h, w = ref.shape
-        if layout == "bgd":
-            store = torch.empty(B, G, D, h, w, device=ref.device, dtype=torch.float32)
-            sb, sg, sd = store.stride(0), store.stride(1), store.stride(2)
-            out = store.permute(0, 2, 1, 3, 4)
-        else:
-            store = torch.empty(B, D, G, h, w, device=ref.device, dtype=torch.float32)
-            sb, sd, sg = store.stride(0), store.stride(1), store.stride(2)
-            out = store
-        _lib.call("md_costvol_fwd", _p(ref), _p(src), _p(K), _p(invK), _p(pose), _p(hyp), _p(prior), _p(ztrans),
-                  float(scale_fac), int(sched_type), B, C, G, h, w, D, _p(store), sb, sd, sg, _stream())
+        store, (sb, sd, sg, sp), out = _vol_alloc(layout, B, D, G, h, w, ref.device)
+        _timed_call("md_costvol_fwd", _p(ref), _p(src), _p(K), _p(invK), _p(pose), _p(hyp), _p(prior), _p(ztrans),
+                    float(scale_fac), int(sched_type), B, C, G, h, w, D, _p(store), sb, sd, sg, sp, _stream())
         ctx.save_for_backward(ref, src, K, invK, pose, hyp if hyp is not None else torch.empty(0),
                               prior if prior is not None else torch.empty(0),
                               ztrans if ztrans is not None else torch.empty(0))
@@ -89,18 +148,11 @@ class _CostVolume(torch.autograd.Function):
         ref, src, K, invK, pose, hyp, prior, ztrans = ctx.saved_tensors
         scale_fac, sched_type, G, D, layout, has_hyp, has_prior, has_z = ctx.meta
         B, C, h, w = ref.shape
-        if layout == "bgd":
-            g = gout.permute(0, 2, 1, 3, 4).contiguous()  # no copy when the consumer produced (B,G,D,h,w)
-            sb, sg, sd = g.stride(0), g.stride(1), g.stride(2)
-        else:
-            g = gout.contiguous()
-            sb, sd, sg = g.stride(0), g.stride(1), g.stride(2)
-        if g.dtype != torch.float32:
-            g = g.float()
+        g, (sb, sd, sg, sp) = _vol_as_layout(gout.float(), layout)  # no copy when the consumer kept the layout
         d_ref, d_src = torch.empty_like(ref), torch.empty_like(src)
-        _lib.call("md_costvol_bwd", _p(g), sb, sd, sg, _p(ref), _p(src), _p(K), _p(invK), _p(pose),
-                  _p(hyp if has_hyp else None), _p(prior if has_prior else None), _p(ztrans if has_z else None),
-                  scale_fac, sched_type, B, C, G, h, w, D, _p(d_ref), _p(d_src), _stream())
+        _timed_call("md_costvol_bwd", _p(g), sb, sd, sg, sp, _p(ref), _p(src), _p(K), _p(invK), _p(pose),
+                    _p(hyp if has_hyp else None), _p(prior if has_prior else None), _p(ztrans if has_z else None),
+                    scale_fac, sched_type, B, C, G, h, w, D, _p(d_ref), _p(d_src), _stream())
         return (d_ref, d_src) + (None,) * 11
 
 
@@ -123,36 +175,31 @@ class _FuseVolumes(torch.autograd.Function):
     @staticmethod
     def forward(ctx, layout, *vols):
         N = len(vols)
-        if layout == "bgd":
-            vs = [v.permute(0, 2, 1, 3, 4).contiguous() for v in vols]  # storage (B,G,D,h,w)
-            B, G, D, h, w = vs[0].shape
-            sb, sg, sd = vs[0].stride(0), vs[0].stride(1), vs[0].stride(2)
-        else:
-            vs = [v.contiguous() for v in vols]
-            B, D, G, h, w = vs[0].shape
-            sb, sd, sg = vs[0].stride(0), vs[0].stride(1), vs[0].stride(2)
+        B, D, G, h, w = vols[0].shape
+        vs, strides = [], None
+        for v in vols:
+            st, strides = _vol_as_layout(v, layout)
+            vs.append(st)
+        sb, sd, sg, sp = strides
         store = torch.empty_like(vs[0])
         weights = torch.empty(N, B, h, w, device=store.device, dtype=torch.float32)
         arr = (ctypes.c_void_p * N)(*[v.data_ptr() for v in vs])
-        _lib.call("md_fuse_fwd", arr, N, B, D, G, h * w, sb, sd, sg, _p(store), _p(weights), _stream())
+        _lib.call("md_fuse_fwd", arr, N, B, D, G, h * w, sb, sd, sg, sp, _p(store), _p(weights), _stream())
         ctx.save_for_backward(*vs)
-        ctx.meta = (layout, N, B, D, G, h, w, sb, sd, sg)
+        ctx.meta = (layout, N, B, D, G, h, w, sb, sd, sg, sp)
         ctx.mark_non_differentiable(weights)
-        out = store.permute(0, 2, 1, 3, 4) if layout == "bgd" else store
-        return out, weights
+        return _vol_logical(store, layout), weights
 
     @staticmethod
     def backward(ctx, gout, _gw):
         vs = ctx.saved_tensors
-        layout, N, B, D, G, h, w, sb, sd, sg = ctx.meta
-        g = (gout.permute(0, 2, 1, 3, 4) if layout == "bgd" else gout).contiguous().float()
+        layout, N, B, D, G, h, w, sb, sd, sg, sp = ctx.meta
+        g, _ = _vol_as_layout(gout.float(), layout)
         ds = [torch.empty_like(v) for v in vs]
         arr = (ctypes.c_void_p * N)(*[v.data_ptr() for v in vs])
         darr = (ctypes.c_void_p * N)(*[d.data_ptr() for d in ds])
-        _lib.call("md_fuse_bwd", _p(g), arr, N, B, D, G, h * w, sb, sd, sg, darr, _stream())
-        if layout == "bgd":
-            ds = [d.permute(0, 2, 1, 3, 4) for d in ds]
-        return (None,) + tuple(ds)
+        _lib.call("md_fuse_bwd", _p(g), arr, N, B, D, G, h * w, sb, sd, sg, sp, darr, _stream())
+        return (None,) + tuple(_vol_logical(d, layout) for d in ds)
 
 
 def fuse_volumes(vols, layout="bgd", exact_single_frame=False):

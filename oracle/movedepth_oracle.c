@@ -233,6 +233,28 @@ static inline void tap_scatter(float *img, int w, int h, const tap_t *t, float g
     if (vx1 && vy1) img[y1 * w + x1] += g * (t->wy1 * t->wx1);
 }
 
+static inline void tap_scatter_atomic(float *img, int w, int h, const tap_t *t, float g) {
+    float wx0 = 1.f - t->wx1, wy0 = 1.f - t->wy1;
+    int x0 = t->x0, y0 = t->y0, x1 = x0 + 1, y1 = y0 + 1;
+    int vx0 = x0 >= 0 && x0 < w, vx1 = x1 >= 0 && x1 < w, vy0 = y0 >= 0 && y0 < h, vy1 = y1 >= 0 && y1 < h;
+    if (vx0 && vy0) {
+#pragma omp atomic
+        img[y0 * w + x0] += g * (wy0 * wx0);
+    }
+    if (vx1 && vy0) {
+#pragma omp atomic
+        img[y0 * w + x1] += g * (wy0 * t->wx1);
+    }
+    if (vx0 && vy1) {
+#pragma omp atomic
+        img[y1 * w + x0] += g * (t->wy1 * wx0);
+    }
+    if (vx1 && vy1) {
+#pragma omp atomic
+        img[y1 * w + x1] += g * (t->wy1 * t->wx1);
+    }
+}
+
 /* ------------------------------------------------------------------ plane-sweep cost volume */
 
 /* generate_costvol, layers.py:778-794.  ref, src [B,C,h,w]; K, invK [B,16]; hyp [B,D,h,w]; pose [B,16]
@@ -299,12 +321,12 @@ void mdo_costvol_grouped_bwd(const float *gout, const float *ref, const float *s
     int hw = h * w, n = C / G;
     memset(d_ref, 0, sizeof(float) * (size_t)B * C * hw);
     memset(d_src, 0, sizeof(float) * (size_t)B * C * hw);
-#pragma omp parallel for schedule(static)
-    for (int b = 0; b < B; ++b) {
-        float P[12];
-        kt_rows(K + b * 16, pose + b * 16, P);
-        for (int d = 0; d < D; ++d)
-            for (int y = 0; y < h; ++y)
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int b = 0; b < B; ++b)
+        for (int y = 0; y < h; ++y) {
+            float P[12];
+            kt_rows(K + b * 16, pose + b * 16, P);
+            for (int d = 0; d < D; ++d)
                 for (int x = 0; x < w; ++x) {
                     int p = y * w + x;
                     float gx, gy;
@@ -314,11 +336,11 @@ void mdo_costvol_grouped_bwd(const float *gout, const float *ref, const float *s
                     for (int c = 0; c < C; ++c) {
                         float g = gout[(((size_t)b * D + d) * G + (c % G)) * hw + p] / (float)n;
                         size_t o = ((size_t)b * C + c) * hw;
-                        d_ref[o + p] += g * tap_sample(src + o, w, h, &t);
-                        tap_scatter(d_src + o, w, h, &t, g * ref[o + p]);
+                        d_ref[o + p] += g * tap_sample(src + o, w, h, &t); /* row y is owned by this thread */
+                        tap_scatter_atomic(d_src + o, w, h, &t, g * ref[o + p]);
                     }
                 }
-    }
+        }
 }
 
 /* Confidence-weighted frame fusion, trainer.py:349-363.

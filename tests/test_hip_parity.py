@@ -60,7 +60,7 @@ def test_schedule_golden(ops, ty):
 COSTVOL_CASES = ["small", "white", "oob", "zv2", "c64g8"]
 
 
-@pytest.mark.parametrize("layout", ["bgd", "bdg"])
+@pytest.mark.parametrize("layout", ["bgd", "bdg", "ndhwc"])
 @pytest.mark.parametrize("tag", COSTVOL_CASES)
 def test_costvol_golden(ops, tag, layout):
     g = load_golden("costvol_" + tag)
@@ -90,14 +90,15 @@ def test_costvol_ungrouped_golden(ops):
     assert_close(host(vol), g["cost_vol_full0"])
 
 
-def test_costvol_twoframe_golden(ops):
+@pytest.mark.parametrize("layout", ["bgd", "ndhwc"])
+def test_costvol_twoframe_golden(ops, layout):
     g = load_golden("costvol_twoframe")
     G = int(g["G"])
     ref = dev(g["ref"], True)
     srcs = [dev(g["src%d" % f], True) for f in range(2)]
     vols = [ops.costvol_grouped(ref, srcs[f], dev(g["K"]), dev(g["invK"]), dev(g["pose"][:, f]), G,
-                                depth_priors=dev(g["hyp"])) for f in range(2)]
-    cor, w = ops.fuse_volumes(vols)
+                                depth_priors=dev(g["hyp"]), layout=layout) for f in range(2)]
+    cor, w = ops.fuse_volumes(vols, layout=layout)
     assert_close(host(cor), g["cor_feats"], what="two-frame cor_feats")
     for f in range(2):
         assert_close(host(w[f]), g["cor_weight%d" % f], rtol=1e-5)
@@ -114,8 +115,8 @@ def test_costvol_twoframe_golden(ops):
     dict(B=1, C=32, G=32, h=12, w=20, D=5, rot=0.02, trans=0.1),              # ungrouped
     dict(B=1, C=64, G=16, h=12, w=20, D=5, rot=0.02, trans=0.1),              # 4 channels per group
 ])
-@pytest.mark.parametrize("fused", [False, True])
-def test_costvol_vs_oracle(ops, oracle_lib, case, fused):
+@pytest.mark.parametrize("fused,layout", [(False, "bgd"), (True, "bgd"), (True, "ndhwc")])
+def test_costvol_vs_oracle(ops, oracle_lib, case, fused, layout):
     rng = np.random.default_rng(7)
     B, C, G, h, w, D = (case[k] for k in "BCGhwD")
     ref = smooth_field(rng, (B, C, h, w), 3, -1, 1)
@@ -131,9 +132,9 @@ def test_costvol_vs_oracle(ops, oracle_lib, case, fused):
     r, s = dev(ref, True), dev(src, True)
     if fused:  # schedule evaluated inside the kernel
         vol = ops.costvol_grouped(r, s, dev(K), dev(invK), dev(pose), G, prior=dev(prior), ndepth=D, scale_fac=0.3,
-                                  z_trans=dev(z), type="inverse")
+                                  z_trans=dev(z), type="inverse", layout=layout)
     else:
-        vol = ops.costvol_grouped(r, s, dev(K), dev(invK), dev(pose), G, depth_priors=dev(hyp))
+        vol = ops.costvol_grouped(r, s, dev(K), dev(invK), dev(pose), G, depth_priors=dev(hyp), layout=layout)
     assert_close(host(vol), exp, what="volume")
     (vol * dev(gout)).sum().backward()
     assert_close(host(r.grad), exp_dref, what="d_ref")
@@ -152,7 +153,7 @@ def test_costvol_full_size_properties(ops):
     src = torch.randn(B, C, h, w, device="cuda")
     prior = 2 + 20 * torch.rand(B, 1, h, w, device="cuda")
     eye = torch.eye(4, device="cuda").repeat(B, 1, 1)
-    kw = dict(prior=prior, ndepth=D, scale_fac=0.3, type="inverse")
+    kw = dict(prior=prior, ndepth=D, scale_fac=0.3, type="inverse", layout="ndhwc")
     vol = ops.costvol_grouped(ref, src, K, invK, eye, G, **kw)
     exp = (ref * src).reshape(B, 2, G, h, w).mean(1)[:, None].expand(B, D, G, h, w)
     assert float((vol - exp).abs().max()) < 5e-4  # coordinate round trip is not bit exact (SURVEY KAT1)
