@@ -98,6 +98,11 @@ def main():
         raise SystemExit("launch --gpus %d with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (a.gpus, a.gpus, world))
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # MIOpen's find results / compiled kernels for reg3d's 3-D convs (saves ~70 s of solver search per process)
+    mc = os.path.join(ROOT, "movedepth_amd", "miopen_cache")
+    if os.path.isdir(mc) and os.access(mc, os.W_OK):
+        os.environ.setdefault("MIOPEN_USER_DB_PATH", os.path.join(mc, "db"))
+        os.environ.setdefault("MIOPEN_CUSTOM_CACHE_DIR", os.path.join(mc, "cache"))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
 
     from movedepth_amd import ops

@@ -121,21 +121,24 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(const float *__restrict__
 }
 
 // Deterministic second stage: sum the per-block dP partials of a sample, then dT = K[:3,:]^T dP.
+// The partials cancel heavily (sum |terms| >> |sum|), so this stage accumulates in fp64.
 __global__ __launch_bounds__(256) void warp_bwd_finish_kernel(const float *__restrict__ ws, const float *__restrict__ K,
                                                               int nblk, float *__restrict__ d_T) {
-    __shared__ float red[4][12];
-    __shared__ float dP[12];
+    __shared__ double red[4][12];
+    __shared__ double dP[12];
     const int b = blockIdx.x;
-    float acc[12];
+    double acc[12];
 #pragma unroll
-    for (int i = 0; i < 12; ++i) acc[i] = 0.f;
+    for (int i = 0; i < 12; ++i) acc[i] = 0.0;
     for (int k = threadIdx.x; k < nblk; k += 256)
 #pragma unroll
-        for (int i = 0; i < 12; ++i) acc[i] += ws[((size_t)b * nblk + k) * 12 + i];
+        for (int i = 0; i < 12; ++i) acc[i] += (double)ws[((size_t)b * nblk + k) * 12 + i];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
     for (int i = 0; i < 12; ++i) {
-        const float s = md_wave_sum(acc[i]);
+        double s = acc[i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
         if (lane == 0) red[wave][i] = s;
     }
     __syncthreads();
@@ -143,9 +146,9 @@ __global__ __launch_bounds__(256) void warp_bwd_finish_kernel(const float *__res
     __syncthreads();
     if (threadIdx.x < 16) {
         const int k = threadIdx.x / 4, j = threadIdx.x % 4;
-        float s = 0.f;
-        for (int i = 0; i < 3; ++i) s += K[b * 16 + i * 4 + k] * dP[i * 4 + j];
-        d_T[b * 16 + threadIdx.x] = s;
+        double s = 0.0;
+        for (int i = 0; i < 3; ++i) s += (double)K[b * 16 + i * 4 + k] * dP[i * 4 + j];
+        d_T[b * 16 + threadIdx.x] = (float)s;
     }
 }
 

@@ -290,6 +290,11 @@ class FPN4(nn.Module):
         return self.out(f), (c3, c2, c1, c0)[3 - self.scale]
 
 
+def _set_benchmark(value, grad):
+    torch.backends.cudnn.benchmark = value
+    return grad
+
+
 class ConvBnReLU3D(nn.Module):
     def __init__(self, cin, cout, kernel_size=3, stride=1, pad=1):
         super().__init__()
@@ -329,7 +334,28 @@ class reg3d(nn.Module):
         self.conv11 = _up3d(2 * c, c)
         self.prob = nn.Conv3d(c, 1, 3, stride=1, padding=1, bias=False)
 
+    # MIOpen solver search ("find") only for this module's convolutions: without it the fp32 3-D convs fall back to
+    # naive kernels (1.67 s fwd+bwd), with it for every conv of the model the first step takes ~18 min of kernel
+    # compilation.  torch reads the benchmark flag when a conv (or its backward) executes, so it is switched on
+    # around the forward and, through tensor hooks, around this module's part of the backward pass.
+    find_convs = True
+
     def forward(self, inputs):
+        if not self.find_convs or not inputs.is_cuda:
+            return self._forward(inputs)
+        prev = torch.backends.cudnn.benchmark
+        if inputs.requires_grad:
+            inputs.register_hook(lambda g: _set_benchmark(prev, g))      # fires after this module's backward
+        torch.backends.cudnn.benchmark = True
+        try:
+            out = self._forward(inputs)
+        finally:
+            torch.backends.cudnn.benchmark = prev
+        if out.requires_grad:
+            out.register_hook(lambda g: _set_benchmark(True, g))         # fires before this module's backward
+        return out
+
+    def _forward(self, inputs):
         x = inputs.permute(0, 2, 1, 3, 4)  # B,D,G,h,w -> B,G,D,h,w (a view)
         # channels_last_3d (NDHWC) when the module was converted to it: MIOpen's fp32 3-D convolutions are ~75x
         # faster in that layout on gfx950 (21.6 ms vs 1.67 s fwd+bwd at 6x16x96x48x160); no copy if the volume was

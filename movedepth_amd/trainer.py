@@ -75,9 +75,9 @@ class Trainer:
         if opt.convex_up:
             self.models["up"] = networks.convex_upsample_layer(feature_dim=8 * 2 ** opt.prior_scale, scale=opt.prior_scale)
             main.append("up")
-        # library convolutions: let MIOpen search its solvers once per shape, and give the 3-D regulariser the
-        # channels-last layout its fast kernels need (its input volume is written in that layout by the HIP kernel)
-        torch.backends.cudnn.benchmark = bool(opt.miopen_find)
+        # library convolutions: the 3-D regulariser runs channels-last (its input volume is written in that layout by
+        # the HIP kernel) with MIOpen's solver search enabled for its convs only (see networks.reg3d)
+        self.models["reg3d"].find_convs = bool(opt.miopen_find)
         self.vol_layout = "bgd"
         if opt.reg3d_channels_last and opt.num_depth_bins >= 8:
             self.models["reg3d"] = self.models["reg3d"].to(memory_format=torch.channels_last_3d)

@@ -209,7 +209,9 @@ def test_warp_vs_oracle_fullres(ops, oracle_lib):
     assert_close(host(out), exp)
     (out * dev(gout)).sum().backward()
     assert_close_knife_edge(host(d.grad).reshape(exp_dd.shape), exp_dd, rtol=2e-4, what="d_depth")
-    assert_close(host(t.grad), exp_dT, rtol=2e-4, what="d_T")
+    # d_T sums 122,880 per-pixel terms that cancel to ~1% of their absolute sum; the per-block partial sums are
+    # fp32 (as is the reference's sgemm over the same axis), the oracle accumulates in fp64
+    assert_close(host(t.grad), exp_dT, rtol=1e-3, what="d_T")
 
 
 @pytest.mark.parametrize("hw", [(4, 8), (8, 16), (16, 32), (32, 64)])

@@ -1,0 +1,151 @@
+"""GPU parity of the Trainer-level path (generate_images_pred + compute_losses + compute_fuse_losses) against
+golden vectors produced by the reference's own Trainer methods (tools/gen_golden.py: losses_mono / losses_mvs_*).
+Tolerance 1e-4 relative (north star), gradients norm-wise."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import assert_close, assert_close_knife_edge, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a, grad=False):
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32).cuda().requires_grad_(grad)
+
+
+def host(t):
+    return t.detach().float().cpu().numpy()
+
+
+def make_trainer(**flags):
+    from movedepth_amd.trainer import Trainer
+
+    t = Trainer.__new__(Trainer)
+    opt = dict(no_ssim=False, ssim_lw=0.85, scales=[0, 1, 2, 3], frame_ids=[0, -1, 1], height=32, width=64,
+               min_depth=0.1, max_depth=100.0, disable_automasking=False, disparity_smoothness=1e-3,
+               mask_mvs_auto=False, mask_mvs_conf=False, mask_mvs_dist=False, mask_mvs_geo=False,
+               mvs_smooth_loss=False, automask_noise="host")
+    opt.update(flags)
+    t.opt = types.SimpleNamespace(**opt)
+    t.device = torch.device("cuda", 0)
+    t.num_scales = 4
+    return t
+
+
+def golden_inputs(g):
+    inputs = {}
+    for f in (0, -1, 1):
+        for s in range(4):
+            inputs[("color", f, s)] = dev(g["in_color_%d_%d" % (f, s)])
+    for s in range(4):
+        inputs[("K", s)], inputs[("inv_K", s)] = dev(g["in_K_%d" % s]), dev(g["in_inv_K_%d" % s])
+    return inputs
+
+
+def test_mono_losses_match_reference():
+    from movedepth_amd.layers import transformation_from_parameters
+
+    g = load_golden("losses_mono")
+    t = make_trainer()
+    inputs = golden_inputs(g)
+    disps = {s: dev(g["disp_%d" % s], True) for s in range(4)}
+    aa = {-1: dev(g["axisangle_m1"], True), 1: dev(g["axisangle_p1"], True)}
+    tr = {-1: dev(g["translation_m1"], True), 1: dev(g["translation_p1"], True)}
+    outputs = {("disp", s): disps[s] for s in range(4)}
+    for f in (-1, 1):
+        outputs[("cam_T_cam", 0, f)] = transformation_from_parameters(aa[f], tr[f], invert=(f < 0))
+        assert_close(host(outputs[("cam_T_cam", 0, f)]), g["T_m1" if f < 0 else "T_p1"], rtol=1e-6)
+    t.generate_images_pred(inputs, outputs)
+    for s in range(4):
+        assert_close(host(outputs[("depth", 0, s)]), g["depth_0_%d" % s], rtol=1e-5)
+    assert_close(host(outputs[("sample", -1, 0)]), g["sample_m1_0"], rtol=1e-5)
+    assert_close(host(outputs[("color", 1, 0)]), g["color_p1_0"])
+    assert_close(host(outputs[("color", -1, 3)]), g["color_m1_3"])
+    torch.manual_seed(int(g["noise_seed"]))  # host-mode tie-break noise: same draws as the reference
+    losses = t.compute_losses(inputs, outputs)
+    for s in range(4):
+        assert abs(float(losses["loss/%d" % s]) - float(g["loss_%d" % s])) < 1e-4 * float(g["loss_%d" % s])
+        assert abs(float(losses["mono_smooth_loss/%d" % s]) - float(g["smooth_%d" % s])) < 1e-4 * float(g["smooth_%d" % s])
+    assert abs(float(losses["loss"]) - float(g["loss"])) < 1e-4 * float(g["loss"])
+    assert_close(host(outputs["mono_reproj_loss"]), g["mono_reproj_loss"])
+    losses["loss"].backward()
+    for s in range(4):
+        assert_close_knife_edge(host(disps[s].grad), g["d_disp_%d" % s], rtol=5e-4, max_outlier_frac=5e-3,
+                                what="d_disp_%d" % s)
+    for f, n in ((-1, "m1"), (1, "p1")):
+        assert_close(host(aa[f].grad), g["d_axisangle_" + n], rtol=2e-3, what="d_axisangle")
+        assert_close(host(tr[f].grad), g["d_translation_" + n], rtol=2e-3, what="d_translation")
+
+
+def test_mono_losses_without_automask():
+    g, gm = load_golden("losses_mono_noautomask"), load_golden("losses_mono")
+    t = make_trainer(disable_automasking=True)
+    inputs = golden_inputs(gm)
+    outputs = {("disp", s): dev(gm["disp_%d" % s]) for s in range(4)}
+    outputs[("cam_T_cam", 0, -1)], outputs[("cam_T_cam", 0, 1)] = dev(gm["T_m1"]), dev(gm["T_p1"])
+    t.generate_images_pred(inputs, outputs)
+    losses = t.compute_losses(inputs, outputs)
+    for s in range(4):
+        assert abs(float(losses["loss/%d" % s]) - float(g["loss_%d" % s])) < 1e-4 * float(g["loss_%d" % s])
+    assert abs(float(losses["loss"]) - float(g["loss"])) < 1e-4 * float(g["loss"])
+
+
+@pytest.mark.parametrize("tag,flags", [("default", {}), ("auto_smooth", dict(mask_mvs_auto=True, mvs_smooth_loss=True))])
+def test_mvs_and_fuse_losses_match_reference(tag, flags):
+    g, gm = load_golden("losses_mvs_" + tag), load_golden("losses_mono")
+    t = make_trainer(**flags)
+    inputs = golden_inputs(gm)
+    depth_mvs, trust = dev(g["depth_mvs"], True), dev(g["trust_mono_mask"], True)
+    mono_depth = dev(g["mono_depth"])
+    outputs = {"depth_mvs": depth_mvs, ("cam_T_cam", 0, -1): dev(g["T_m1"]), ("cam_T_cam", 0, 1): dev(g["T_p1"])}
+    outputs["fused_depth"] = (1 - trust) * depth_mvs[:, None].detach() + trust * mono_depth
+    torch.manual_seed(int(g["noise_seed"]))
+    fuse_losses = t.compute_fuse_losses(inputs, outputs)
+    t.generate_images_pred(inputs, outputs, is_mvs=True)
+    mvs_losses = t.compute_losses(inputs, outputs, is_mvs=True)
+    assert abs(float(fuse_losses["loss"]) - float(g["fuse_loss"])) < 1e-4 * float(g["fuse_loss"])
+    assert abs(float(mvs_losses["loss"]) - float(g["mvs_loss"])) < 1e-4 * float(g["mvs_loss"])
+    assert abs(float(outputs["mvs_reproj_loss"]) - float(g["mvs_reproj_loss"])) < 1e-4 * float(g["mvs_reproj_loss"])
+    assert_close(host(outputs["mvs_reprojection_loss"]), g["mvs_reprojection_loss"])
+    assert_close(host(outputs[("mvs_color", -1)]), g["mvs_color_m1"])
+    assert_close(host(outputs[("mvs_color_fuse", 1)]), g["mvs_color_fuse_p1"])
+    assert (host(outputs[("mvs_mask", -1)]).astype(bool) != g["mvs_mask_m1"]).mean() < 2e-3
+    if "mvs_smooth_loss" in g:
+        assert abs(float(mvs_losses["mvs_smooth_loss/0"]) - float(g["mvs_smooth_loss"])) < 1e-4 * float(g["mvs_smooth_loss"])
+    (mvs_losses["loss"] + fuse_losses["loss"]).backward()
+    assert_close_knife_edge(host(depth_mvs.grad), g["d_depth_mvs"], rtol=5e-4, max_outlier_frac=5e-3, what="d_depth_mvs")
+    assert_close_knife_edge(host(trust.grad), g["d_trust"], rtol=5e-4, max_outlier_frac=5e-3, what="d_trust")
+
+
+def test_process_batch_runs_and_has_reference_keys():
+    """End-to-end step at BASELINE config 1 shape (64x128, D=16, B=1): output / loss keys of the reference
+     are present, the loss is finite and every parameter receives a finite gradient."""
+    from movedepth_amd.options import MovedepthOptions
+    from movedepth_amd.synthetic import make_inputs
+    from movedepth_amd.trainer import Trainer
+
+    opt = MovedepthOptions().parse(["--height", "64", "--width", "128", "--num_depth_bins", "16", "--batch_size", "1",
+                                    "--convex_up", "--weights_init", "scratch", "--miopen_find", "0"])
+    torch.manual_seed(0)
+    np.random.seed(0)
+    t = Trainer(opt)
+    t.set_train()
+    inputs = make_inputs(1, 64, 128, opt.frame_ids, seed=0, device=t.device)
+    outputs, losses = t.process_batch(inputs, is_train=True)
+    for k in [("disp", 0), ("depth", 0, 0), ("sample", -1, 0), ("color", 1, 3), ("color_identity", -1, 0),
+              ("cam_T_cam", 0, -1), ("axisangle", 0, 1), ("translation", 0, 1), ("mvs_color", -1), ("mvs_mask", 1),
+              ("mvs_color_fuse", 1), "depth_mvs", "masked_depth", "masked_aug", "fused_depth", "trust_mono_mask",
+              "mono_reproj_loss", "mvs_reprojection_loss", "mvs_reproj_loss", "reprojection_loss_mask"]:
+        assert k in outputs, k
+    for k in ["loss", "loss/0", "loss/3", "mono_smooth_loss/0", "masked_loss", "fuse_reproj_loss"]:
+        assert k in losses, k
+    assert ("relative_pose", -1) in inputs
+    assert outputs["depth_mvs"].shape == (1, 64, 128)
+    assert torch.isfinite(losses["loss"])
+    losses["loss"].backward()
+    for name, m in t.models.items():
+        for pn, p in m.named_parameters():
+            assert p.grad is not None and torch.isfinite(p.grad).all(), (name, pn)
