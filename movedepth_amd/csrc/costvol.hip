@@ -46,7 +46,6 @@ struct CvDims {
     int B, C, G, h, w, D;
     int tiles_x, tiles, splits;  // pixel tiles per sample (x, total) and channel splits
     int items;                   // B * tiles * splits work items of D hypotheses each
-    int dbg;  // tuning only (MD_COSTVOL_DEBUG bitmask); 0 in production
     long long sb, sd, sg, sp;
 };
 
@@ -541,7 +540,7 @@ __global__ __launch_bounds__(256) void costvol_bwd_kernel(const float *__restric
                 t.w00 = t.w01 = t.w10 = t.w11 = 0.f;
             }
             if (t.x0 != bx || t.y0 != by) {
-                if (bx != INT_MIN && !(dm.dbg & 1)) {
+                if (bx != INT_MIN) {
                     const int lx = bx - ox, ly = by - oy;
                     if ((unsigned)lx < (unsigned)(T::WW - 1) && (unsigned)ly < (unsigned)(T::WH - 1)) {
                         float *g = gw + ly * T::WW + lx;
@@ -574,7 +573,7 @@ __global__ __launch_bounds__(256) void costvol_bwd_kernel(const float *__restric
     // flush the d_src window (cells outside the image are grid_sample's zero padding: dropped)
     for (int idx = tid; idx < CPW * WP; idx += 256) {
         const float v = gw[idx];
-        if (v == 0.f || (dm.dbg & 2)) continue;
+        if (v == 0.f) continue;
         const int k = idx / WP, cell = idx % WP;
         const int sx = ox + cell % T::WW, sy = oy + cell / T::WW;
         if (sx >= 0 && sx < dm.w && sy >= 0 && sy < dm.h)
@@ -622,7 +621,6 @@ int launch(const CvPtrs &q, CvDims dm, hipStream_t stream) {
     const int TW = tw_env == 64 ? 64 : 32;
     const int TH = 256 / TW;
     dm.tiles_x = md_cdiv(dm.w, TW);
-    dm.dbg = env_int("MD_COSTVOL_DEBUG", 0);
     const int tiles = dm.tiles_x * md_cdiv(dm.h, TH);
     const int splits = dm.G / GS;
     // Grid: every work item (sample, tile, channel split) is cut into `dsplit` equal hypothesis slices, one
