@@ -99,10 +99,19 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     # MIOpen's find results / compiled kernels for reg3d's 3-D convs (saves ~70 s of solver search per process)
+    # (a private copy per rank: MIOpen's sqlite caches are not meant to be shared by concurrent writers)
     mc = os.path.join(ROOT, "movedepth_amd", "miopen_cache")
-    if os.path.isdir(mc) and os.access(mc, os.W_OK):
-        os.environ.setdefault("MIOPEN_USER_DB_PATH", os.path.join(mc, "db"))
-        os.environ.setdefault("MIOPEN_CUSTOM_CACHE_DIR", os.path.join(mc, "cache"))
+    if os.path.isdir(mc) and "MIOPEN_USER_DB_PATH" not in os.environ:
+        import shutil
+        import tempfile
+
+        priv = os.path.join(tempfile.gettempdir(), "movedepth_miopen_rank%d_%d" % (rank, os.getpid()))
+        try:
+            shutil.copytree(mc, priv, dirs_exist_ok=True)
+            os.environ["MIOPEN_USER_DB_PATH"] = os.path.join(priv, "db")
+            os.environ["MIOPEN_CUSTOM_CACHE_DIR"] = os.path.join(priv, "cache")
+        except OSError:
+            pass
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
 
     from movedepth_amd import ops
@@ -115,6 +124,9 @@ def main():
             "--local_rank", str(local_rank)]
     if world > 1:
         argv.append("--ddp")
+    share_gpu = os.environ.get("MD_SHARE_GPU", "0") == "1"
+    if share_gpu:
+        argv[argv.index("--local_rank") + 1] = "0"
     opt = MovedepthOptions().parse(argv)
     torch.manual_seed(1234 + rank)
     import numpy as np
@@ -126,6 +138,7 @@ def main():
     inputs = make_inputs(opt.batch_size, opt.height, opt.width, opt.frame_ids, seed=rank, device=dev)  # resident in HBM
 
     def barrier():
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -139,7 +152,7 @@ def main():
         _, losses = trainer.train_step(dict(inputs))
     barrier()
     elapsed = time.perf_counter() - t0
-    loss_val = float(losses["loss"])
+    loss_val = float(losses["loss"].detach())
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -43,7 +43,8 @@ class GradSync:
         flat = torch.zeros(n, dtype=ps[0].dtype, device=ps[0].device)
         off = 0
         for p in ps:
-            p.grad = flat[off:off + p.numel()].view_as(p)  # gradient storage IS the bucket
+            # gradient storage IS the bucket; same (dense) strides as the parameter, e.g. channels_last_3d weights
+            p.grad = flat[off:off + p.numel()].as_strided(p.size(), p.stride())
             off += p.numel()
         self.buckets.append((flat, ps))
 

@@ -39,12 +39,15 @@ class Trainer:
             raise RuntimeError("movedepth_amd runs its hot path on HIP kernels: a GPU is required (no CPU fallback)")
 
         self.local_rank = self.opt.local_rank
-        torch.cuda.set_device(self.local_rank)
-        self.device = torch.device("cuda", self.local_rank)
+        # MD_SHARE_GPU=1 (testing on a 1-GPU box only): every rank uses device 0 and the gloo backend
+        share_gpu = os.environ.get("MD_SHARE_GPU", "0") == "1"
+        dev_index = 0 if share_gpu else self.local_rank
+        torch.cuda.set_device(dev_index)
+        self.device = torch.device("cuda", dev_index)
         self.rank, self.world_size = 0, 1
         if self.opt.ddp:
             if not dist.is_initialized():
-                dist.init_process_group(backend="nccl")  # RCCL over xGMI
+                dist.init_process_group(backend="gloo" if share_gpu else "nccl")  # "nccl" = RCCL over xGMI
             self.rank, self.world_size = dist.get_rank(), dist.get_world_size()
 
         self.num_scales = len(self.opt.scales)
@@ -83,7 +86,7 @@ class Trainer:
             self.models["reg3d"] = self.models["reg3d"].to(memory_format=torch.channels_last_3d)
             self.vol_layout = "ndhwc"
         for k, m in self.models.items():
-            if opt.ddp and opt.sync_bn:
+            if opt.ddp and opt.sync_bn and not share_gpu:
                 m = torch.nn.SyncBatchNorm.convert_sync_batchnorm(m)
             self.models[k] = m.to(self.device)
         for k in main:

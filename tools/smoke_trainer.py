@@ -15,6 +15,6 @@ for i in range(3):
     t0 = time.time()
     out, losses = t.train_step(dict(inp))
     torch.cuda.synchronize()
-    print("step", i, "loss %.5f" % float(losses["loss"]), {k: round(float(v), 5) for k, v in losses.items() if k != "loss"}, "%.3fs" % (time.time() - t0))
+    print("step", i, "loss %.5f" % float(losses["loss"].detach()), {k: round(float(v.detach()), 5) for k, v in losses.items() if k != "loss"}, "%.3fs" % (time.time() - t0))
 assert all(torch.isfinite(p.grad).all() for m in t.models.values() for p in m.parameters() if p.grad is not None)
 print("keys", sorted(str(k) for k in out.keys())[:12], "...")
