@@ -64,11 +64,18 @@ using vecf = float __attribute__((ext_vector_type(CPW)));
 using v2f = float __attribute__((ext_vector_type(2)));
 
 
-// channel held in LDS slot k of this workgroup: slot k = j*N + i  ->  channel i*G + gbase + j
-template <int N>
-__device__ __forceinline__ int slot_channel(int k, int G, int gbase) {
-    return (k % N) * G + gbase + k / N;
-}
+// Channel slots of a workgroup (GS groups x N channels each, group j = channels {gbase+j + i*G}).
+// Quad map (GS % 4 == 0): 16-byte quad q = m*N + i holds channel i of groups 4m..4m+3, so a group-quad's outputs
+// are N packed multiply-adds of whole quads and come out as 4 consecutive groups in aligned registers (no
+// shuffling before the wide store).  Otherwise slot k = j*N + i.
+template <int GS, int N>
+struct Slots {
+    static constexpr bool QUADMAP = GS % 4 == 0;
+    __device__ __forceinline__ static constexpr int group(int k) { return QUADMAP ? 4 * ((k / 4) / N) + k % 4 : k / N; }
+    __device__ __forceinline__ static constexpr int chan_in_group(int k) { return QUADMAP ? (k / 4) % N : k % N; }
+    __device__ __forceinline__ static constexpr int slot(int j, int i) { return QUADMAP ? ((j / 4) * N + i) * 4 + j % 4 : j * N + i; }
+    __device__ __forceinline__ static int channel(int k, int G, int gbase) { return chan_in_group(k) * G + gbase + group(k); }
+};
 
 // A segment = hypotheses [d0, d1) of one work item (sample, pixel tile, channel split).  The grid is sized to
 // the chip's workgroup slots and every workgroup takes an equal, contiguous share of the items x D hypothesis
@@ -144,7 +151,7 @@ __device__ __noinline__ vecf<CPW> sample_slow(const float *__restrict__ srcb, in
     const bool vx0 = x0 >= 0, vx1 = x1 < w, vy0 = y0 >= 0, vy1 = y1 < h;
 #pragma unroll
     for (int k = 0; k < CPW; ++k) {
-        const float *pl = srcb + (size_t)slot_channel<N>(k, G, gbase) * hw;
+        const float *pl = srcb + (size_t)Slots<CPW / N, N>::channel(k, G, gbase) * hw;
         float s = 0.f;
         if (vx0 && vy0) s += pl[y0 * w + x0] * w00;
         if (vx1 && vy0) s += pl[y0 * w + x1] * w01;
@@ -165,7 +172,7 @@ __device__ __noinline__ void scatter_slow(float *__restrict__ dsrcb, int h, int 
     if (!((vx0 || vx1) && (vy0 || vy1))) return;
 #pragma unroll
     for (int k = 0; k < CPW; ++k) {
-        float *pl = dsrcb + (size_t)slot_channel<N>(k, G, gbase) * hw;
+        float *pl = dsrcb + (size_t)Slots<CPW / N, N>::channel(k, G, gbase) * hw;
         if (vx0 && vy0) unsafeAtomicAdd(pl + y0 * w + x0, a0[k]);
         if (vx1 && vy0) unsafeAtomicAdd(pl + y0 * w + x1, a1[k]);
         if (vx0 && vy1) unsafeAtomicAdd(pl + y1 * w + x0, a2[k]);
@@ -197,6 +204,68 @@ __device__ __forceinline__ vecf<CPW> sample_window(const float4 *win, const Tap4
         S = sample_slow<CPW, N>(srcb, h, w, G, gbase, t.x0, t.y0, t.w00, t.w01, t.w10, t.w11);
     }
     return S;
+}
+
+// In-window fast path: bilinear samples of all CPW channels from the LDS window, multiplied by the ref features
+// (1/N folded in) and summed per group.  og[j] = group j's output.
+template <int GS, int N, int TW>
+__device__ __forceinline__ void groups_from_window(const float4 *wp, const Tap4 &t, const vecf<GS * N> &rf, float (&og)[GS]) {
+    constexpr int CPW = GS * N, QPP = CPW / 4;
+    using T = Tile<TW, CPW>;
+    using SL = Slots<GS, N>;
+    const v2f w00 = t.w00, w01 = t.w01, w10 = t.w10, w11 = t.w11;  // broadcast pairs -> v_pk_fma_f32
+    if (SL::QUADMAP) {
+#pragma unroll
+        for (int m = 0; m < GS / 4; ++m) {
+            v2f olo = 0.f, ohi = 0.f;
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                const int q = m * N + i;
+                // (issuing all 4*QPP tap reads up front was tried: 187-256 VGPRs, one wave per SIMD less, slower)
+                const float4 a00 = wp[q * T::WP], a01 = wp[q * T::WP + 1];
+                const float4 a10 = wp[q * T::WP + T::WW], a11 = wp[q * T::WP + T::WW + 1];
+                // two channels per packed instruction (a quad's .xy / .zw sit in aligned register pairs)
+                const v2f lo = v2f{a00.x, a00.y} * w00 + v2f{a01.x, a01.y} * w01 + v2f{a10.x, a10.y} * w10 + v2f{a11.x, a11.y} * w11;
+                const v2f hi = v2f{a00.z, a00.w} * w00 + v2f{a01.z, a01.w} * w01 + v2f{a10.z, a10.w} * w10 + v2f{a11.z, a11.w} * w11;
+                olo += lo * v2f{rf[q * 4 + 0], rf[q * 4 + 1]};
+                ohi += hi * v2f{rf[q * 4 + 2], rf[q * 4 + 3]};
+            }
+            og[4 * m + 0] = olo.x; og[4 * m + 1] = olo.y; og[4 * m + 2] = ohi.x; og[4 * m + 3] = ohi.y;
+        }
+    } else {
+        float S[CPW];
+#pragma unroll
+        for (int q = 0; q < QPP; ++q) {
+            const float4 a00 = wp[q * T::WP], a01 = wp[q * T::WP + 1];
+            const float4 a10 = wp[q * T::WP + T::WW], a11 = wp[q * T::WP + T::WW + 1];
+            S[q * 4 + 0] = (a00.x * t.w00 + a01.x * t.w01 + a10.x * t.w10 + a11.x * t.w11) * rf[q * 4 + 0];
+            S[q * 4 + 1] = (a00.y * t.w00 + a01.y * t.w01 + a10.y * t.w10 + a11.y * t.w11) * rf[q * 4 + 1];
+            S[q * 4 + 2] = (a00.z * t.w00 + a01.z * t.w01 + a10.z * t.w10 + a11.z * t.w11) * rf[q * 4 + 2];
+            S[q * 4 + 3] = (a00.w * t.w00 + a01.w * t.w01 + a10.w * t.w10 + a11.w * t.w11) * rf[q * 4 + 3];
+        }
+#pragma unroll
+        for (int j = 0; j < GS; ++j) {
+            float acc = 0.f;
+#pragma unroll
+            for (int i = 0; i < N; ++i) acc += S[SL::slot(j, i)];
+            og[j] = acc;
+        }
+    }
+}
+
+// Slow path (tap outside the staged window): group outputs from bounds-checked global loads.
+template <int GS, int N>
+__device__ __forceinline__ void groups_from_global(const float *__restrict__ srcb, int h, int w, int G, int gbase, const Tap4 &t,
+                                                   const vecf<GS * N> &rf, float (&og)[GS]) {
+    using SL = Slots<GS, N>;
+    const vecf<GS * N> S = sample_slow<GS * N, N>(srcb, h, w, G, gbase, t.x0, t.y0, t.w00, t.w01, t.w10, t.w11);
+#pragma unroll
+    for (int j = 0; j < GS; ++j) {
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < N; ++i) acc += S[SL::slot(j, i)] * rf[SL::slot(j, i)];
+        og[j] = acc;
+    }
 }
 
 // Tile set-up shared by forward and backward: the thread's pixel and walk state, the window origin, and the
@@ -267,21 +336,34 @@ __device__ __forceinline__ bool tile_setup(const float *__restrict__ src, const 
     const int spanx = mxx - mnx + 1, spany = mxy - mny + 1;
     ox = spanx <= T::WW ? mnx : mnx + (spanx - T::WW) / 2;
     oy = spany <= T::WH ? mny : mny + (spany - T::WH) / 2;
-    // stage the window: consecutive threads -> consecutive columns (coalesced per channel plane)
+    // stage the window: consecutive threads -> consecutive columns (coalesced per channel plane).  Four quads
+    // (16 loads) are issued before the first LDS write so the L2 round trips overlap instead of queueing
+    // (the staging loop used to be ~a quarter of the kernel: 15 dependent round trips per workgroup).
     const float *srcb = src + (size_t)b * dm.C * hw;
-    for (int idx = tid; idx < T::WP * QPP; idx += 256) {
-        const int wx = idx % T::WW, rest = idx / T::WW;
-        const int wy = rest % T::WH, q = rest / T::WH;
-        const int sx = ox + wx, sy = oy + wy;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (sx >= 0 && sx < dm.w && sy >= 0 && sy < dm.h) {
-            const size_t o = (size_t)sy * dm.w + sx;
-            v.x = srcb[(size_t)slot_channel<N>(q * 4 + 0, dm.G, gbase) * hw + o];
-            v.y = srcb[(size_t)slot_channel<N>(q * 4 + 1, dm.G, gbase) * hw + o];
-            v.z = srcb[(size_t)slot_channel<N>(q * 4 + 2, dm.G, gbase) * hw + o];
-            v.w = srcb[(size_t)slot_channel<N>(q * 4 + 3, dm.G, gbase) * hw + o];
+    constexpr int NQ = T::WP * QPP, NIT = (NQ + 255) / 256, UNR = 4;
+#pragma unroll
+    for (int it0 = 0; it0 < NIT; it0 += UNR) {
+        float4 v[UNR];
+        int dst[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int idx = tid + (it0 + u) * 256;
+            const int wx = idx % T::WW, rest = idx / T::WW;
+            const int wy = rest % T::WH, q = rest / T::WH;
+            const int sx = ox + wx, sy = oy + wy;
+            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            dst[u] = (it0 + u < NIT && idx < NQ) ? q * T::WP + wy * T::WW + wx : -1;
+            if (dst[u] >= 0 && sx >= 0 && sx < dm.w && sy >= 0 && sy < dm.h) {
+                const size_t o = (size_t)sy * dm.w + sx;
+                v[u].x = srcb[(size_t)Slots<GS, N>::channel(q * 4 + 0, dm.G, gbase) * hw + o];
+                v[u].y = srcb[(size_t)Slots<GS, N>::channel(q * 4 + 1, dm.G, gbase) * hw + o];
+                v[u].z = srcb[(size_t)Slots<GS, N>::channel(q * 4 + 2, dm.G, gbase) * hw + o];
+                v[u].w = srcb[(size_t)Slots<GS, N>::channel(q * 4 + 3, dm.G, gbase) * hw + o];
+            }
         }
-        win[q * T::WP + wy * T::WW + wx] = v;
+#pragma unroll
+        for (int u = 0; u < UNR; ++u)
+            if (dst[u] >= 0) win[dst[u]] = v[u];
     }
     __syncthreads();
     return valid;
@@ -314,7 +396,7 @@ __global__ __launch_bounds__(256) void costvol_fwd_kernel(const float *__restric
     if (valid) {
 #pragma unroll
         for (int k = 0; k < CPW; ++k)
-            rf[k] = ref[((size_t)b * dm.C + slot_channel<N>(k, dm.G, gbase)) * hw + p] * (1.f / (float)N);
+            rf[k] = ref[((size_t)b * dm.C + Slots<GS, N>::channel(k, dm.G, gbase)) * hw + p] * (1.f / (float)N);
     }
     float *outp = out + (size_t)b * dm.sb + (size_t)gbase * dm.sg + (size_t)d0 * dm.sd + (size_t)p * dm.sp;
     float dnext = valid ? wk.hypothesis(itv, d0) : 1.f;
@@ -323,44 +405,13 @@ __global__ __launch_bounds__(256) void costvol_fwd_kernel(const float *__restric
         if (d + 1 < d1) dnext = wk.hypothesis(itv, d + 1);
         const Tap4 t = wk.tap_at(dep);
         const int lx = t.x0 - ox, ly = t.y0 - oy;
-        const bool in_win = (unsigned)lx < (unsigned)(T::WW - 1) && (unsigned)ly < (unsigned)(T::WH - 1);
-        if (in_win) {
-            // channels go through in 16-byte quads (one LDS plane per quad: neighbouring lanes read neighbouring
-            // 16-byte slots, conflict free, and every tap address is the same base + an immediate offset);
-            // a group's output is emitted as soon as its N channels are in
-            const float4 *wp = win + ly * T::WW + lx;
-            const v2f w00 = t.w00, w01 = t.w01, w10 = t.w10, w11 = t.w11;  // broadcast pairs -> v_pk_fma_f32
-            float acc = 0.f;
+        float og[GS];
+        if ((unsigned)lx < (unsigned)(T::WW - 1) && (unsigned)ly < (unsigned)(T::WH - 1))
+            groups_from_window<GS, N, TW>(win + ly * T::WW + lx, t, rf, og);
+        else
+            groups_from_global<GS, N>(srcb, dm.h, dm.w, dm.G, gbase, t, rf, og);
 #pragma unroll
-            for (int q = 0; q < QPP; ++q) {
-                const float4 a00 = wp[q * T::WP], a01 = wp[q * T::WP + 1];
-                const float4 a10 = wp[q * T::WP + T::WW], a11 = wp[q * T::WP + T::WW + 1];
-                // two channels per packed instruction (a quad's .xy / .zw sit in aligned register pairs)
-                const v2f lo = v2f{a00.x, a00.y} * w00 + v2f{a01.x, a01.y} * w01 + v2f{a10.x, a10.y} * w10 + v2f{a11.x, a11.y} * w11;
-                const v2f hi = v2f{a00.z, a00.w} * w00 + v2f{a01.z, a01.w} * w01 + v2f{a10.z, a10.w} * w10 + v2f{a11.z, a11.w} * w11;
-                const v2f plo = lo * v2f{rf[q * 4 + 0], rf[q * 4 + 1]}, phi = hi * v2f{rf[q * 4 + 2], rf[q * 4 + 3]};
-                const float S4[4] = {plo.x, plo.y, phi.x, phi.y};  // already multiplied by ref/N
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int k = q * 4 + e;
-                    acc += S4[e];
-                    if (k % N == N - 1) {
-                        const int j = k / N;  // group done
-                        outp[(size_t)j * dm.sg] = acc;
-                        acc = 0.f;
-                    }
-                }
-            }
-        } else {
-            const vecf<CPW> S = sample_window<CPW, N, TW>(win, t, ox, oy, srcb, dm.h, dm.w, dm.G, gbase);
-#pragma unroll
-            for (int j = 0; j < GS; ++j) {
-                float acc = 0.f;
-#pragma unroll
-                for (int i = 0; i < N; ++i) acc += S[j * N + i] * rf[j * N + i];
-                outp[(size_t)j * dm.sg] = acc;
-            }
-        }
+        for (int j = 0; j < GS; ++j) outp[(size_t)j * dm.sg] = og[j];
         outp += dm.sd;
     }
     __syncthreads();  // the window is restaged by the next segment
@@ -407,7 +458,7 @@ __global__ __launch_bounds__(256) void costvol_fwd_nhwc_kernel(const float *__re
     if (valid) {
 #pragma unroll
         for (int k = 0; k < CPW; ++k)
-            rf[k] = ref[((size_t)b * dm.C + slot_channel<N>(k, dm.G, gbase)) * hw + p] * (1.f / (float)N);
+            rf[k] = ref[((size_t)b * dm.C + Slots<GS, N>::channel(k, dm.G, gbase)) * hw + p] * (1.f / (float)N);
     }
     // write-back roles: store k of this lane covers 16-byte piece (k*64 + lane) of the wave's block
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -433,35 +484,10 @@ __global__ __launch_bounds__(256) void costvol_fwd_nhwc_kernel(const float *__re
             if (d + 1 < d1) dnext = wk.hypothesis(itv, d + 1);
             const Tap4 t = wk.tap_at(dep);
             const int lx = t.x0 - ox, ly = t.y0 - oy;
-            if ((unsigned)lx < (unsigned)(T::WW - 1) && (unsigned)ly < (unsigned)(T::WH - 1)) {
-                const float4 *wp = win + ly * T::WW + lx;
-                const v2f w00 = t.w00, w01 = t.w01, w10 = t.w10, w11 = t.w11;
-                float acc = 0.f;
-#pragma unroll
-                for (int q = 0; q < QPP; ++q) {
-                    const float4 a00 = wp[q * T::WP], a01 = wp[q * T::WP + 1];
-                    const float4 a10 = wp[q * T::WP + T::WW], a11 = wp[q * T::WP + T::WW + 1];
-                    const v2f lo = v2f{a00.x, a00.y} * w00 + v2f{a01.x, a01.y} * w01 + v2f{a10.x, a10.y} * w10 + v2f{a11.x, a11.y} * w11;
-                    const v2f hi = v2f{a00.z, a00.w} * w00 + v2f{a01.z, a01.w} * w01 + v2f{a10.z, a10.w} * w10 + v2f{a11.z, a11.w} * w11;
-                    const v2f plo = lo * v2f{rf[q * 4 + 0], rf[q * 4 + 1]}, phi = hi * v2f{rf[q * 4 + 2], rf[q * 4 + 3]};
-                    const float S4[4] = {plo.x, plo.y, phi.x, phi.y};
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int k = q * 4 + e;
-                        acc += S4[e];
-                        if (k % N == N - 1) { og[k / N] = acc; acc = 0.f; }
-                    }
-                }
-            } else {
-                const vecf<CPW> S = sample_slow<CPW, N>(srcb, dm.h, dm.w, dm.G, gbase, t.x0, t.y0, t.w00, t.w01, t.w10, t.w11);
-#pragma unroll
-                for (int j = 0; j < GS; ++j) {
-                    float acc = 0.f;
-#pragma unroll
-                    for (int i = 0; i < N; ++i) acc += S[j * N + i] * rf[j * N + i];
-                    og[j] = acc;
-                }
-            }
+            if ((unsigned)lx < (unsigned)(T::WW - 1) && (unsigned)ly < (unsigned)(T::WH - 1))
+                groups_from_window<GS, N, TW>(win + ly * T::WW + lx, t, rf, og);
+            else
+                groups_from_global<GS, N>(srcb, dm.h, dm.w, dm.G, gbase, t, rf, og);
         } else {
 #pragma unroll
             for (int j = 0; j < GS; ++j) og[j] = 0.f;
@@ -513,7 +539,7 @@ __global__ __launch_bounds__(256) void costvol_bwd_kernel(const float *__restric
         vecf<CPW> rf, dref = 0.f;
 #pragma unroll
         for (int k = 0; k < CPW; ++k)
-            rf[k] = ref[((size_t)b * dm.C + slot_channel<N>(k, dm.G, gbase)) * hw + p] * (1.f / (float)N);
+            rf[k] = ref[((size_t)b * dm.C + Slots<GS, N>::channel(k, dm.G, gbase)) * hw + p] * (1.f / (float)N);
         vecf<CPW> a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;  // pending d_src quad at cell (bx, by)
         int bx = INT_MIN, by = INT_MIN;
         const float *gp = gout + (size_t)b * dm.sb + (size_t)gbase * dm.sg + (size_t)d0 * dm.sd + (size_t)p * dm.sp;
@@ -532,8 +558,8 @@ __global__ __launch_bounds__(256) void costvol_bwd_kernel(const float *__restric
                 const vecf<CPW> S = sample_window<CPW, N, TW>(win, t, ox, oy, srcb, dm.h, dm.w, dm.G, gbase);
 #pragma unroll
                 for (int k = 0; k < CPW; ++k) {
-                    dref[k] += gq[k / N] * S[k];
-                    gv[k] = gq[k / N] * rf[k];
+                    dref[k] += gq[Slots<GS, N>::group(k)] * S[k];
+                    gv[k] = gq[Slots<GS, N>::group(k)] * rf[k];
                 }
             } else {
                 t.x0 = INT_MIN; t.y0 = INT_MIN;  // sentinel iteration: forces the final flush
@@ -563,7 +589,7 @@ __global__ __launch_bounds__(256) void costvol_bwd_kernel(const float *__restric
         float *drp = d_ref + (size_t)b * dm.C * hw + p;
 #pragma unroll
         for (int k = 0; k < CPW; ++k) {
-            float *o = drp + (size_t)slot_channel<N>(k, dm.G, gbase) * hw;
+            float *o = drp + (size_t)Slots<GS, N>::channel(k, dm.G, gbase) * hw;
             const float v = dref[k] * (1.f / (float)N);  // the group mean's 1/N (rf carries it on the d_src side)
             if (d0 == 0 && d1 == dm.D) *o = v;  // this segment is the pixel's only contributor
             else unsafeAtomicAdd(o, v);
@@ -577,7 +603,7 @@ __global__ __launch_bounds__(256) void costvol_bwd_kernel(const float *__restric
         const int k = idx / WP, cell = idx % WP;
         const int sx = ox + cell % T::WW, sy = oy + cell / T::WW;
         if (sx >= 0 && sx < dm.w && sy >= 0 && sy < dm.h)
-            unsafeAtomicAdd(dsrcb + (size_t)slot_channel<N>(k, dm.G, gbase) * hw + (size_t)sy * dm.w + sx, v);
+            unsafeAtomicAdd(dsrcb + (size_t)Slots<GS, N>::channel(k, dm.G, gbase) * hw + (size_t)sy * dm.w + sx, v);
     }
     __syncthreads();  // gw / win are reused by the next segment
     }
