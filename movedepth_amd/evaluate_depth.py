@@ -1,0 +1,90 @@
+"""Inference path of the reference's evaluate_depth.py on the same HIP kernels, forward only.
+
+`predict_depth` restates the inline forward of evaluate_depth.py:181-256 (mono prior -> velocity-guided hypotheses
+-> plane-sweep volume -> reg3d -> softmax + localmax -> convex upsample); `compute_errors` is :22-40.  Reference
+quirks kept: the hypothesis range uses the z-translation of batch element 0 for the whole batch (:218); with more
+than one lookup frame the confidence weight is softmax over D of the mean over G (:236), not the training variant
+(App. B-7).  The KITTI reader / ground-truth files are out of scope here; `evaluate` takes any iterable of input
+dicts (movedepth_amd.synthetic.SyntheticLoader by default) and an optional ground-truth callback.
+"""
+import numpy as np
+import torch
+
+from . import ops
+from .layers import disp_to_depth, transformation_from_parameters
+
+
+def compute_errors(gt, pred):
+    """abs_rel, sq_rel, rmse, rmse_log, a1, a2, a3 (reference evaluate_depth.py:22-40)"""
+    thresh = np.maximum((gt / pred), (pred / gt))
+    a1, a2, a3 = (thresh < 1.25).mean(), (thresh < 1.25 ** 2).mean(), (thresh < 1.25 ** 3).mean()
+    rmse = np.sqrt(((gt - pred) ** 2).mean())
+    rmse_log = np.sqrt(((np.log(gt) - np.log(pred)) ** 2).mean())
+    abs_rel = np.mean(np.abs(gt - pred) / gt)
+    sq_rel = np.mean(((gt - pred) ** 2) / gt)
+    return abs_rel, sq_rel, rmse, rmse_log, a1, a2, a3
+
+
+@torch.no_grad()
+def predict_depth(models, data, opt, vol_layout="ndhwc"):
+    """-> dict(depth_mvs (B,H,W), disp_mono (B,H,W), relative_poses (B,N,4,4)).  `models`: the trainer's dict."""
+    dev = next(models["mono_encoder"].parameters()).device
+    data = {k: v.to(dev) for k, v in data.items()}
+    color = data[("color", 0, 0)]
+    output = models["mono_depth"](models["mono_encoder"](color))
+    frames = list(opt.frame_ids)
+    for fi in frames[1:]:
+        pair = [data["color", fi, 0], data["color", 0, 0]] if fi < 0 else [data["color", 0, 0], data["color", fi, 0]]
+        axisangle, translation = models["pose"]([models["pose_encoder"](torch.cat(pair, 1))])
+        data[("relative_pose", fi)] = transformation_from_parameters(axisangle[:, 0], translation[:, 0], invert=fi < 0)
+    # NB: the reference stacks over frames_to_load[1:] and indexes by matching frame; identical for the defaults
+    relative_poses = torch.stack([data[("relative_pose", idx)] for idx in opt.matching_ids[1:]], 1)
+    ref_feat, ref_context = models["mvs_encoder"](color)
+    src_feats = [models["mvs_encoder"](data["color_aug", f_i, 0])[0] for f_i in opt.matching_ids[1:]]
+
+    disp_prior = output[("disp", opt.prior_scale)]
+    depth_prior = 1 / (1 / opt.max_depth + disp_prior * (1 / opt.min_depth - 1 / opt.max_depth))
+    B = color.shape[0]
+    z_trans = (opt.z_scale * relative_poses[0, 0, 2, -1]).reshape(1).repeat(B).contiguous()  # sample 0's z for all
+    hyp = ops.schedule_depth_range(depth_prior, opt.num_depth_bins, opt.depth_bin_fac, z_trans, "inverse")
+    vols = [ops.costvol_grouped(ref_feat, src_feats[f], data[("K", 2)], data[("inv_K", 2)], relative_poses[:, f],
+                                opt.reg3d_c, prior=depth_prior, ndepth=opt.num_depth_bins, scale_fac=opt.depth_bin_fac,
+                                z_trans=z_trans, type="inverse", layout=vol_layout) for f in range(len(src_feats))]
+    if len(vols) == 1:
+        cor = vols[0]  # w/(1e-8 + w): identity to 1.6e-7
+    else:
+        wsum, cor = 1e-8, 0
+        for v in vols:  # evaluation-time confidence: softmax over D of the group mean (evaluate_depth.py:236)
+            w = torch.softmax(v.mean(2), dim=1).max(1)[0]
+            wsum = wsum + w
+            cor = cor + w.unsqueeze(1).unsqueeze(1) * v
+        cor = cor / wsum.unsqueeze(1).unsqueeze(1)
+    logits = models["reg3d"](cor)
+    depth_mvs, _, _ = ops.softmax_entropy_localmax(logits, 1 / hyp[:, -1], 1 / hyp[:, 0], opt.norm_radius)
+    if opt.convex_up:
+        depth_mvs = models["up"](depth_mvs, ref_context)
+    disp_mono, _ = disp_to_depth(output[("disp", 0)], opt.min_depth, opt.max_depth)
+    return {"depth_mvs": depth_mvs, "disp_mono": disp_mono[:, 0], "relative_poses": relative_poses}
+
+
+def evaluate(trainer, loader, gt_fn=None, min_depth=1e-3, max_depth=80.0, median_scaling=True):
+    """Runs predict_depth over `loader`; with gt_fn(batch_index, inputs) -> (B,H,W) ground-truth depth (numpy)
+    returns the mean of the 7 metrics after the reference's median scaling / clamping (:262-331), else None."""
+    trainer.set_eval()
+    errors = []
+    preds = []
+    for i, data in enumerate(loader):
+        out = predict_depth(trainer.models, data, trainer.opt, getattr(trainer, "vol_layout", "ndhwc"))
+        pred = out["depth_mvs"].cpu().numpy()
+        preds.append(pred)
+        if gt_fn is None:
+            continue
+        gt = gt_fn(i, data)
+        for b in range(pred.shape[0]):
+            mask = np.logical_and(gt[b] > min_depth, gt[b] < max_depth)
+            p, g = pred[b][mask], gt[b][mask]
+            if median_scaling:
+                p = p * np.median(g) / np.median(p)
+            errors.append(compute_errors(g, np.clip(p, min_depth, max_depth)))
+    trainer.set_train()
+    return (np.array(errors).mean(0) if errors else None), np.concatenate(preds)

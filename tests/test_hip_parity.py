@@ -173,8 +173,8 @@ def test_costvol_full_size_properties(ops):
     g = torch.randn_like(v)
     (v * g).sum().backward()
     lhs = float((v.detach().double() * g.double()).sum())
-    assert abs(float((r.double() * r.grad.double()).sum()) - lhs) < 1e-4 * abs(lhs)
-    assert abs(float((s.double() * s.grad.double()).sum()) - lhs) < 1e-4 * abs(lhs)
+    assert abs(float((r.detach().double() * r.grad.double()).sum()) - lhs) < 1e-4 * abs(lhs)
+    assert abs(float((s.detach().double() * s.grad.double()).sum()) - lhs) < 1e-4 * abs(lhs)
 
 
 # ------------------------------------------------------------------ warp

@@ -149,3 +149,46 @@ def test_process_batch_runs_and_has_reference_keys():
     for name, m in t.models.items():
         for pn, p in m.named_parameters():
             assert p.grad is not None and torch.isfinite(p.grad).all(), (name, pn)
+
+
+def test_eval_path_matches_training_forward_and_checkpoint_roundtrip(tmp_path):
+    """evaluate_depth's inline forward gives the same MVS depth as process_batch under eval mode
+    (B=1, velocity-guided schedule active), and save_model/load_model round-trips every sub-model file."""
+    import os
+
+    from movedepth_amd.evaluate_depth import compute_errors, predict_depth
+    from movedepth_amd.options import MovedepthOptions
+    from movedepth_amd.synthetic import make_inputs
+    from movedepth_amd.trainer import Trainer
+
+    opt = MovedepthOptions().parse(["--height", "64", "--width", "128", "--num_depth_bins", "16", "--batch_size", "1",
+                                    "--convex_up", "--weights_init", "scratch", "--miopen_find", "0",
+                                    "--log_dir", str(tmp_path), "--model_name", "rt"])
+    torch.manual_seed(1)
+    np.random.seed(1)
+    t = Trainer(opt)
+    t.epoch = opt.ztrans_start_epc + 1  # velocity-guided range, as evaluation always uses it
+    t.set_eval()
+    inputs = make_inputs(1, 64, 128, opt.frame_ids, seed=3, device=t.device)
+    with torch.no_grad():
+        outputs, _ = t.process_batch(dict(inputs))
+    pred = predict_depth(t.models, dict(inputs), opt, t.vol_layout)
+    assert_close(host(pred["depth_mvs"]), host(outputs["depth_mvs"]), rtol=1e-5)
+    e = compute_errors(np.array([1.0, 2.0, 4.0]), np.array([1.0, 2.0, 4.0]))
+    assert e[0] == 0 and e[2] == 0 and e[4] == 1.0
+    # checkpoints: same file names / keys as the reference; reload restores identical weights
+    t.epoch = 17
+    t.save_model()
+    folder = os.path.join(str(tmp_path), "rt", "models", "weights_17")
+    names = sorted(os.listdir(folder))
+    assert names == sorted([m + ".pth" for m in t.models] + ["adam.pth"])
+    sd = torch.load(os.path.join(folder, "mono_encoder.pth"), map_location="cpu")
+    assert "encoder.conv1.weight" in sd and "encoder.layer4.1.bn2.running_var" in sd and sd["height"] == 64
+    before = {k: v.detach().clone() for k, v in t.models["reg3d"].state_dict().items()}
+    with torch.no_grad():
+        for p in t.models["reg3d"].parameters():
+            p.add_(1.0)
+    opt.load_weights_folder = folder
+    t.load_model()
+    for k, v in t.models["reg3d"].state_dict().items():
+        assert torch.equal(v, before[k]), k

@@ -7,6 +7,8 @@ constexpr int B = 6, D = 96, G = 16, H = 48, W = 160, TW = 32, TH = 8;
 // mode 0: planar (B,G,D,h,w), lane = pixel, 16 dword stores per step
 // mode 1: ndhwc (B,D,h,w,G), coalesced dwordx4: lane l of store k -> piece k*64+l of the wave's 64px x 64B block
 // mode 2: ndhwc, lane = pixel writes its own 64 B as 4 dwordx4 (strided)
+// mode 4: ndhwc, two waves share a pixel row piece: each writes 32-byte halves of the 64-byte pixel records (lane l -> pixel l/2, chunk l%2)
+// mode 5: ndhwc via 4-lane quads: each store writes whole 64-byte records at a 256-byte stride
 // mode 3: planar but each wave-step writes dwordx4 along x (4 px per lane, 16 lanes per row piece) - idealised wide planar
 template <int MODE>
 __global__ __launch_bounds__(256) void k(float *out, int dsplit) {
@@ -34,6 +36,24 @@ __global__ __launch_bounds__(256) void k(float *out, int dsplit) {
                 float4 *dst = reinterpret_cast<float4 *>(out + ((((size_t)b * D + d) * H + y) * W + x) * G + c * 4);
                 *dst = make_float4(v, v + 1, v + 2, v + c);
             }
+        } else if (MODE == 4) {
+            // 128 px per WG (32x4): waves 0,1 -> half 0, waves 2,3 -> half 1; wave covers 64 px (2 rows)
+            const int half = wave >> 1, wrow = (wave & 1) * 2;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int L = kk * 64 + lane, pw = L / 2, ch = L % 2;
+                const int px = tx0 + pw % TW, py = (ty0 / 2) + wrow + pw / TW;   // tile height 4 -> ty0/2
+                float4 *dst = reinterpret_cast<float4 *>(out + ((((size_t)b * D + d) * H + py) * W + px) * G + half * 8 + ch * 4);
+                *dst = make_float4(v, v + 1, v + 2, v + kk);
+            }
+        } else if (MODE == 5) {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int pw = 4 * (lane / 4) + kk, ch = lane % 4;
+                const int px = tx0 + pw % TW, py = ty0 + wave * 2 + pw / TW;
+                float4 *dst = reinterpret_cast<float4 *>(out + ((((size_t)b * D + d) * H + py) * W + px) * G + ch * 4);
+                *dst = make_float4(v, v + 1, v + 2, v + kk);
+            }
         } else {
             // 16 groups x 64 px per wave-step = 1024 floats = 256 float4: lane handles 4 float4: (g = kk*4 + lane/16, 4 px)
 #pragma unroll
@@ -48,7 +68,7 @@ __global__ __launch_bounds__(256) void k(float *out, int dsplit) {
 }
 template <int MODE>
 float run(float *out, int dsplit, int iters) {
-    dim3 grid((W / TW) * (H / TH), 1, B * dsplit);
+    dim3 grid((W / TW) * (H / TH) * (MODE == 4 ? 2 : 1), 1, B * dsplit);
     hipEvent_t a, b_;
     hipEventCreate(&a); hipEventCreate(&b_);
     for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k<MODE>, grid, dim3(256), 0, 0, out, dsplit);
@@ -63,8 +83,8 @@ int main() {
     float *out; size_t n = (size_t)B * D * G * H * W;
     hipMalloc(&out, n * 4);
     for (int ds : {1, 2, 3, 4, 6, 12}) {
-        float t0 = run<0>(out, ds, 30), t1 = run<1>(out, ds, 30), t2 = run<2>(out, ds, 30), t3 = run<3>(out, ds, 30);
-        printf("dsplit %2d (%4d WGs): planar-dword %.1f us (%.0f GB/s) | ndhwc-coalesced %.1f us (%.0f GB/s) | ndhwc-strided %.1f us (%.0f GB/s) | planar-x4 %.1f us (%.0f GB/s)\n",
+        float t0 = run<0>(out, ds, 30), t1 = run<1>(out, ds, 30), t2 = run<4>(out, ds, 30), t3 = run<5>(out, ds, 30);
+        printf("dsplit %2d (%4d WGs): planar-dword %.1f us (%.0f GB/s) | ndhwc-coalesced %.1f us (%.0f GB/s) | ndhwc-halfrecords %.1f us (%.0f GB/s) | ndhwc-quadrecords %.1f us (%.0f GB/s)\n",
                ds, 30 * 6 * ds, t0, n * 4 / t0 / 1e3, t1, n * 4 / t1 / 1e3, t2, n * 4 / t2 / 1e3, t3, n * 4 / t3 / 1e3);
     }
     return 0;
