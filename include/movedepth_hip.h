@@ -147,6 +147,21 @@ int md_softmax_entropy_localmax_bwd(const float *g_depth, const float *g_entropy
                                     int h, int w, int radius, const float *min_inv, const float *max_inv,
                                     float *d_logits, md_stream_t stream);
 
+/* Convex upsampling (layers.py:200-214): depth [B,h,w], mask [B,9*s*s,h,w] (s = 2**scale) -> out [B,s*h,s*w]
+ * (softmax over the 9 taps of a zero-padded 3x3 unfold).  Backward: d_depth [B,h,w], d_mask like mask. */
+int md_convex_upsample_fwd(const float *depth, const float *mask, int B, int h, int w, int scale, float *out,
+                           md_stream_t stream);
+int md_convex_upsample_bwd(const float *gout, const float *depth, const float *mask, int B, int h, int w, int scale,
+                           float *d_depth, float *d_mask, md_stream_t stream);
+
+/* ---- standalone geometry, for call compatibility (the hot kernels fuse these; forward only) -------
+ * BackprojectDepth.forward (layers.py:581-586): depth [Bs,h*w], invK [nk,4,4] (nk = 1 or Bs) -> cam_points [Bs,4,h*w].
+ * Project3D.forward (layers.py:601-621): points [Bs,4,h*w], K, T [nk,4,4] -> pix [Bs,h,w,2] in [-1,1]. */
+int md_backproject(const float *depth, const float *invK, int Bs, int nk, int h, int w, float *cam_points,
+                   md_stream_t stream);
+int md_project3d(const float *points, const float *K, const float *T, int Bs, int nk, int h, int w, float eps,
+                 float *pix, md_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -42,6 +42,10 @@ SIGNATURES = {
     "md_smooth_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "md_softmax_entropy_localmax_fwd": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "md_softmax_entropy_localmax_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "md_convex_upsample_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "md_convex_upsample_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "md_backproject": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "md_project3d": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp]),
 }
 
 _lib = None

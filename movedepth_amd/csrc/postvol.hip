@@ -120,3 +120,171 @@ extern "C" int md_softmax_entropy_localmax_bwd(const float *g_depth, const float
     MD_CHECK_LAUNCH("md_softmax_entropy_localmax_bwd");
     return MD_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Convex upsampling (reference layers.py:200-214): depth (B,h,w), mask (B, 9*s*s, h, w) with s = 2**scale ->
+// out (B, s*h, s*w): per fine pixel a softmax over 9 mask logits weights the zero-padded 3x3 coarse neighbourhood.
+// The reference materialises softmax(mask) (B,9,s,s,h,w), an unfold and a permuted product; here one thread per
+// fine pixel does it in registers (forward), and the backward is the same walk (d_mask per thread, d_depth as a
+// gather over the s*s x 9 fine pixels that read a coarse pixel: deterministic, no atomics).
+namespace {
+
+__device__ __forceinline__ void cu_softmax9(const float *__restrict__ mask, size_t base, size_t kstride, float (&p)[9]) {
+    float mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { p[k] = mask[base + k * kstride]; mx = fmaxf(mx, p[k]); }
+    float den = 0.f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { p[k] = expf(p[k] - mx); den += p[k]; }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) p[k] /= den;
+}
+
+__global__ __launch_bounds__(256) void convex_up_fwd_kernel(const float *__restrict__ depth, const float *__restrict__ mask,
+                                                            int h, int w, int s, float *__restrict__ out) {
+    const int b = blockIdx.z, H = h * s, W = w * s;
+    const int X = blockIdx.x * 64 + (threadIdx.x & 63), Y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (X >= W || Y >= H) return;
+    const int x = X / s, j = X % s, y = Y / s, i = Y % s;
+    const size_t hw = (size_t)h * w;
+    // mask.view(B, 9, s, s, h, w): channel = (k*s + i)*s + j
+    float p[9];
+    cu_softmax9(mask, ((size_t)b * 9 * s * s + (size_t)i * s + j) * hw + (size_t)y * w + x, (size_t)s * s * hw, p);
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const int yy = y + k / 3 - 1, xx = x + k % 3 - 1;
+        if (yy >= 0 && yy < h && xx >= 0 && xx < w) acc += p[k] * depth[(size_t)b * hw + (size_t)yy * w + xx];
+    }
+    out[((size_t)b * H + Y) * W + X] = acc;
+}
+
+__global__ __launch_bounds__(256) void convex_up_bwd_mask_kernel(const float *__restrict__ gout, const float *__restrict__ depth,
+                                                                 const float *__restrict__ mask, int h, int w, int s,
+                                                                 float *__restrict__ d_mask) {
+    const int b = blockIdx.z, H = h * s, W = w * s;
+    const int X = blockIdx.x * 64 + (threadIdx.x & 63), Y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (X >= W || Y >= H) return;
+    const int x = X / s, j = X % s, y = Y / s, i = Y % s;
+    const size_t hw = (size_t)h * w, kstride = (size_t)s * s * hw;
+    const size_t base = ((size_t)b * 9 * s * s + (size_t)i * s + j) * hw + (size_t)y * w + x;
+    float p[9], v[9];
+    cu_softmax9(mask, base, kstride, p);
+    float dot = 0.f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const int yy = y + k / 3 - 1, xx = x + k % 3 - 1;
+        v[k] = (yy >= 0 && yy < h && xx >= 0 && xx < w) ? depth[(size_t)b * hw + (size_t)yy * w + xx] : 0.f;
+        dot += p[k] * v[k];
+    }
+    const float g = gout[((size_t)b * H + Y) * W + X];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) d_mask[base + k * kstride] = g * p[k] * (v[k] - dot);  // softmax backward
+}
+
+__global__ __launch_bounds__(256) void convex_up_bwd_depth_kernel(const float *__restrict__ gout, const float *__restrict__ mask,
+                                                                  int h, int w, int s, float *__restrict__ d_depth) {
+    const int b = blockIdx.z, H = h * s, W = w * s;
+    const int xx = blockIdx.x * 64 + (threadIdx.x & 63), yy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (xx >= w || yy >= h) return;
+    const size_t hw = (size_t)h * w, kstride = (size_t)s * s * hw;
+    float acc = 0.f;
+    // coarse pixel (yy,xx) is tap k of the fine pixels of coarse cell (y,x) = (yy - k/3 + 1, xx - k%3 + 1)
+    for (int k = 0; k < 9; ++k) {
+        const int y = yy - (k / 3 - 1), x = xx - (k % 3 - 1);
+        if (y < 0 || y >= h || x < 0 || x >= w) continue;
+        for (int i = 0; i < s; ++i)
+            for (int j = 0; j < s; ++j) {
+                float p[9];
+                cu_softmax9(mask, ((size_t)b * 9 * s * s + (size_t)i * s + j) * hw + (size_t)y * w + x, kstride, p);
+                acc += gout[((size_t)b * H + y * s + i) * W + x * s + j] * p[k];
+            }
+    }
+    d_depth[(size_t)b * hw + (size_t)yy * w + xx] = acc;
+}
+
+// Standalone geometry (reference layers.py:556-621) for call compatibility; the hot kernels fuse these.
+__global__ __launch_bounds__(256) void backproject_kernel(const float *__restrict__ depth, const float *__restrict__ invK,
+                                                          int nk, int h, int w, float *__restrict__ cam) {
+    const int b = blockIdx.z, hw = h * w, p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= hw) return;
+    const float *iK = invK + (nk == 1 ? 0 : b) * 16;
+    const float x = (float)(p % w), y = (float)(p / w), d = depth[(size_t)b * hw + p];
+    float *c = cam + (size_t)b * 4 * hw;
+    c[p] = d * (iK[0] * x + iK[1] * y + iK[2]);
+    c[hw + p] = d * (iK[4] * x + iK[5] * y + iK[6]);
+    c[2 * hw + p] = d * (iK[8] * x + iK[9] * y + iK[10]);
+    c[3 * hw + p] = 1.f;
+}
+
+__global__ __launch_bounds__(256) void project3d_kernel(const float *__restrict__ pts, const float *__restrict__ K,
+                                                        const float *__restrict__ T, int nk, int h, int w, float eps,
+                                                        float *__restrict__ pix) {
+    const int b = blockIdx.z, hw = h * w, p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= hw) return;
+    const float *Kb = K + (nk == 1 ? 0 : b) * 16, *Tb = T + (nk == 1 ? 0 : b) * 16;
+    float P[12];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float sacc = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sacc += Kb[i * 4 + k] * Tb[k * 4 + j];
+            P[i * 4 + j] = sacc;
+        }
+    const float *c = pts + (size_t)b * 4 * hw;
+    const float X = c[p], Y = c[hw + p], Z = c[2 * hw + p], Wh = c[3 * hw + p];
+    const float c0 = P[0] * X + P[1] * Y + P[2] * Z + P[3] * Wh, c1 = P[4] * X + P[5] * Y + P[6] * Z + P[7] * Wh,
+                c2 = P[8] * X + P[9] * Y + P[10] * Z + P[11] * Wh;
+    const float zz = c2 + eps;
+    pix[((size_t)b * hw + p) * 2] = (c0 / zz / (float)(w - 1) - 0.5f) * 2.f;
+    pix[((size_t)b * hw + p) * 2 + 1] = (c1 / zz / (float)(h - 1) - 0.5f) * 2.f;
+}
+
+}  // namespace
+
+extern "C" int md_convex_upsample_fwd(const float *depth, const float *mask, int B, int h, int w, int scale, float *out,
+                                      md_stream_t stream) {
+    MD_REQUIRE(depth && mask && out, "md_convex_upsample_fwd: null tensor");
+    MD_REQUIRE(B > 0 && B <= 65535 && h > 0 && w > 0 && scale >= 0 && scale <= 4, "md_convex_upsample_fwd: bad dims");
+    const int s = 1 << scale;
+    hipLaunchKernelGGL(convex_up_fwd_kernel, dim3(md_cdiv(w * s, 64), md_cdiv(h * s, 4), B), dim3(256), 0, (hipStream_t)stream,
+                       depth, mask, h, w, s, out);
+    MD_CHECK_LAUNCH("md_convex_upsample_fwd");
+    return MD_OK;
+}
+
+extern "C" int md_convex_upsample_bwd(const float *gout, const float *depth, const float *mask, int B, int h, int w,
+                                      int scale, float *d_depth, float *d_mask, md_stream_t stream) {
+    MD_REQUIRE(gout && depth && mask && d_depth && d_mask, "md_convex_upsample_bwd: null tensor");
+    MD_REQUIRE(B > 0 && B <= 65535 && h > 0 && w > 0 && scale >= 0 && scale <= 4, "md_convex_upsample_bwd: bad dims");
+    const int s = 1 << scale;
+    hipLaunchKernelGGL(convex_up_bwd_mask_kernel, dim3(md_cdiv(w * s, 64), md_cdiv(h * s, 4), B), dim3(256), 0,
+                       (hipStream_t)stream, gout, depth, mask, h, w, s, d_mask);
+    MD_CHECK_LAUNCH("md_convex_upsample_bwd(mask)");
+    hipLaunchKernelGGL(convex_up_bwd_depth_kernel, dim3(md_cdiv(w, 64), md_cdiv(h, 4), B), dim3(256), 0, (hipStream_t)stream,
+                       gout, mask, h, w, s, d_depth);
+    MD_CHECK_LAUNCH("md_convex_upsample_bwd(depth)");
+    return MD_OK;
+}
+
+extern "C" int md_backproject(const float *depth, const float *invK, int Bs, int nk, int h, int w, float *cam_points,
+                              md_stream_t stream) {
+    MD_REQUIRE(depth && invK && cam_points, "md_backproject: null tensor");
+    MD_REQUIRE(Bs > 0 && Bs <= 65535 && (nk == 1 || nk == Bs) && h > 0 && w > 0, "md_backproject: bad dims");
+    hipLaunchKernelGGL(backproject_kernel, dim3(md_cdiv(h * w, 256), 1, Bs), dim3(256), 0, (hipStream_t)stream, depth, invK, nk,
+                       h, w, cam_points);
+    MD_CHECK_LAUNCH("md_backproject");
+    return MD_OK;
+}
+
+extern "C" int md_project3d(const float *points, const float *K, const float *T, int Bs, int nk, int h, int w, float eps,
+                            float *pix, md_stream_t stream) {
+    MD_REQUIRE(points && K && T && pix, "md_project3d: null tensor");
+    MD_REQUIRE(Bs > 0 && Bs <= 65535 && (nk == 1 || nk == Bs) && h > 1 && w > 1, "md_project3d: bad dims");
+    hipLaunchKernelGGL(project3d_kernel, dim3(md_cdiv(h * w, 256), 1, Bs), dim3(256), 0, (hipStream_t)stream, points, K, T, nk,
+                       h, w, eps, pix);
+    MD_CHECK_LAUNCH("md_project3d");
+    return MD_OK;
+}

@@ -3,11 +3,12 @@ return shapes), re-hosted on the HIP kernels of libmovedepth_hip.so through move
 
 What differs by design, not by accident:
   * the geometry modules (BackprojectDepth / Project3D) are fused into the kernels that consume them
-    (cost volume, photometric warp); the standalone modules below exist for call compatibility;
+    (cost volume, photometric warp); the standalone modules below exist for call compatibility and run small
+    HIP kernels of their own when called without autograd (as generate_costvol does upstream, layers.py:784);
   * generate_costvol returns the reference's (B,D,C,h,w) volume (G == C in the fused kernel); the trainer uses
     generate_costvol_grouped, which never materialises the C axis (SURVEY hard part 2).
-Glue that is not on the measured path (Rodrigues 4x4 from 6 numbers, the 9-tap convex upsample) stays as torch
-ops on the GPU; they are the autograd-visible part of the pose / upsample networks.
+Glue that is not on the measured path (Rodrigues 4x4 from 6 numbers) stays as torch ops on the GPU; it is the
+autograd-visible tail of the pose network.
 """
 import numpy as np
 import torch
@@ -77,6 +78,9 @@ class BackprojectDepth(nn.Module):
         self.register_buffer("ones", torch.ones(batch_size, 1, height * width), persistent=False)
 
     def forward(self, depth, inv_K):
+        if depth.is_cuda and not (torch.is_grad_enabled() and depth.requires_grad):
+            return ops.backproject(depth, inv_K, self.batch_size, self.height, self.width)
+        # differentiable use outside the fused kernels: plain torch ops, same arithmetic
         cam_points = torch.matmul(inv_K[:, :3, :3], self.pix_coords)
         cam_points = depth.view(self.batch_size, 1, -1) * cam_points
         return torch.cat([cam_points, self.ones], 1)
@@ -90,6 +94,8 @@ class Project3D(nn.Module):
         self.batch_size, self.height, self.width, self.eps = batch_size, height, width, eps
 
     def forward(self, points, K, T):
+        if points.is_cuda and not (torch.is_grad_enabled() and (points.requires_grad or T.requires_grad)):
+            return ops.project3d(points, K, T, self.batch_size, self.height, self.width, self.eps)
         P = torch.matmul(K, T)[:, :3, :]
         cam_points = torch.matmul(P, points)
         pix = cam_points[:, :2, :] / (cam_points[:, 2, :].unsqueeze(1) + self.eps)
@@ -169,6 +175,8 @@ def localmax(cost_prob, radius, casbin, min_depth_inverse, max_depth_inverse):
 
 def convex_upsample(depth, mask, scale=2):
     """RAFT-style convex upsampling (reference layers.py:200-214): depth (B,h,w) -> (B, 2**scale*h, 2**scale*w)."""
+    if depth.is_cuda:
+        return ops.convex_upsample(depth, mask, scale)
     if depth.dim() == 3:
         depth = depth.unsqueeze(1)
     B, _, H, W = depth.shape

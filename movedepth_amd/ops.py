@@ -417,3 +417,57 @@ def softmax_entropy_localmax(logits, min_depth_inverse, max_depth_inverse, radiu
     """F.softmax(logits, 1) -> entropy(dim=1, keepdim) + localmax(...) in one pass (reference trainer.py:367-371).
     Returns (depth (B,h,w), entropy (B,1,h,w), prob (B,D,h,w) or None [detached])."""
     return _SoftmaxEntropyLocalmax.apply(logits, min_depth_inverse, max_depth_inverse, radius, want_prob)
+
+
+# --------------------------------------------------------------------------- convex upsample / standalone geometry
+class _ConvexUpsample(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, depth, mask, scale):
+        depth, mask = _prep(depth, "depth"), _prep(mask, "mask")
+        B, h, w = depth.shape[0], depth.shape[-2], depth.shape[-1]
+        s = 2 ** scale
+        out = torch.empty(B, s * h, s * w, device=depth.device, dtype=torch.float32)
+        _lib.call("md_convex_upsample_fwd", _p(depth), _p(mask), B, h, w, int(scale), _p(out), _stream())
+        ctx.save_for_backward(depth, mask)
+        ctx.scale = int(scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        depth, mask = ctx.saved_tensors
+        B, h, w = depth.shape[0], depth.shape[-2], depth.shape[-1]
+        g = g.contiguous().float()
+        d_depth, d_mask = torch.empty_like(depth), torch.empty_like(mask)
+        _lib.call("md_convex_upsample_bwd", _p(g), _p(depth), _p(mask), B, h, w, ctx.scale, _p(d_depth), _p(d_mask),
+                  _stream())
+        return d_depth, d_mask, None
+
+
+def convex_upsample(depth, mask, scale=2):
+    """reference layers.py:200-214: depth (B,h,w) or (B,1,h,w), mask (B,9*4**scale,h,w) -> (B, 2**scale*h, 2**scale*w)."""
+    return _ConvexUpsample.apply(depth, mask, scale)
+
+
+def backproject(depth, inv_K, batch_size, height, width):
+    """BackprojectDepth.forward (reference layers.py:581-586), forward only -> (Bs,4,h*w)."""
+    with torch.no_grad():
+        depth, inv_K = _prep(depth, "depth"), _prep(inv_K, "inv_K")
+        if depth.numel() != batch_size * height * width:
+            raise RuntimeError("depth has %d elements, module was built for %d x %d x %d" %
+                               (depth.numel(), batch_size, height, width))
+        nk = inv_K.reshape(-1, 16).shape[0]
+        out = torch.empty(batch_size, 4, height * width, device=depth.device, dtype=torch.float32)
+        _lib.call("md_backproject", _p(depth), _p(inv_K), batch_size, nk, height, width, _p(out), _stream())
+    return out
+
+
+def project3d(points, K, T, batch_size, height, width, eps=1e-7):
+    """Project3D.forward (reference layers.py:601-621), forward only -> (Bs,h,w,2)."""
+    with torch.no_grad():
+        points, K, T = _prep(points, "points"), _prep(K, "K"), _prep(T, "T")
+        nk = K.reshape(-1, 16).shape[0]
+        if T.reshape(-1, 16).shape[0] != nk:
+            T = T.expand(nk, 4, 4).contiguous() if T.reshape(-1, 16).shape[0] == 1 else T
+        out = torch.empty(batch_size, height, width, 2, device=points.device, dtype=torch.float32)
+        _lib.call("md_project3d", _p(points), _p(K), _p(T), batch_size, nk, height, width, float(eps), _p(out), _stream())
+    return out
