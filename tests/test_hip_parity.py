@@ -294,7 +294,7 @@ def test_smooth_vs_oracle_and_golden(ops, oracle_lib, normalize):
     d = dev(g["disp"], True)
     loss = ops.smooth_loss(d, dev(g["img"]), normalize)
     exp = float(g["smooth_norm"] if normalize else g["smooth_raw"])
-    assert abs(float(loss) - exp) < 1e-5 * exp
+    assert abs(float(loss.detach()) - exp) < 1e-5 * exp
     if normalize:
         loss.backward()
         assert_close(host(d.grad), g["d_disp"])
@@ -305,7 +305,7 @@ def test_smooth_vs_oracle_and_golden(ops, oracle_lib, normalize):
     dd = dev(disp, True)
     l2 = ops.smooth_loss(dd, dev(img), normalize)
     e2 = oracle_lib.smooth_loss(disp, img, normalize)
-    assert abs(float(l2) - e2) < 2e-5 * e2
+    assert abs(float(l2.detach()) - e2) < 2e-5 * e2
     (l2 * 2.0).backward()
     assert_close(host(dd.grad), oracle_lib.smooth_loss_bwd(2.0, disp, img, normalize))
 
@@ -361,3 +361,70 @@ def test_standalone_geometry_modules_golden(ops):
     assert_close(host(pix2), g["pix_coords"], rtol=1e-5)
     pix2.sum().backward()
     assert torch.isfinite(d.grad).all()
+
+
+# ------------------------------------------------------------------ ragged / edge shapes of the plane sweep
+@pytest.mark.parametrize("case", [
+    dict(B=1, C=32, G=16, h=5, w=7, D=3),       # smaller than one tile, odd sizes
+    dict(B=3, C=32, G=16, h=37, w=53, D=5),     # nothing divides the tile; w % 4 != 0 (no 16-byte stores)
+    dict(B=1, C=32, G=16, h=9, w=12, D=300),    # D larger than the LDS interval table: several slices per item
+    dict(B=1, C=32, G=16, h=8, w=16, D=2),      # the minimum the fused schedule accepts
+    dict(B=2, C=16, G=16, h=10, w=20, D=6),     # one channel per group, 16 channels
+    dict(B=1, C=8, G=2, h=10, w=20, D=6),       # 4 channels per group, 2 groups (no group-quad map)
+])
+@pytest.mark.parametrize("layout", ["bdg", "ndhwc"])
+@pytest.mark.parametrize("sched", ["inverse", "linear", "log"])
+def test_costvol_ragged_shapes(ops, oracle_lib, case, layout, sched):
+    rng = np.random.default_rng(29)
+    B, C, G, h, w, D = (case[k] for k in "BCGhwD")
+    ref = smooth_field(rng, (B, C, h, w), 2, -1, 1)
+    src = smooth_field(rng, (B, C, h, w), 2, -1, 1)
+    K, invK = kitti_K(h, w, B)
+    prior = (2 + 20 * rng.random((B, 1, h, w))).astype(np.float32)
+    pose = rand_pose(oracle_lib, rng, B, 0.02, 0.1)
+    z = 30.0 * pose[:, 2, 3]
+    hyp = oracle_lib.schedule_depth_range(prior, D, 0.3, z, sched)
+    # the standalone schedule kernel and the schedule fused into the volume kernel agree with the oracle
+    assert_close(host(ops.schedule_depth_range(dev(prior), D, 0.3, dev(z), sched)), hyp, rtol=1e-5)
+    exp = oracle_lib.costvol_grouped(ref, src, K, invK, hyp, pose, G)
+    gout = rng.standard_normal(exp.shape).astype(np.float32)
+    exp_dref, exp_dsrc = oracle_lib.costvol_grouped_bwd(gout, ref, src, K, invK, hyp, pose)
+    r, s = dev(ref, True), dev(src, True)
+    vol = ops.costvol_grouped(r, s, dev(K), dev(invK), dev(pose), G, prior=dev(prior), ndepth=D, scale_fac=0.3,
+                              z_trans=dev(z), type=sched, layout=layout)
+    assert vol.shape == exp.shape
+    assert_close(host(vol), exp, what="volume")
+    (vol * dev(gout)).sum().backward()
+    assert_close(host(r.grad), exp_dref, what="d_ref")
+    assert_close(host(s.grad), exp_dsrc, what="d_src")
+
+
+def test_costvol_single_hypothesis_and_bad_range(ops, oracle_lib):
+    """D = 1 (hypotheses passed explicitly) and the reference's unguarded 1 + f*z <= 0 range:
+    negative / non-finite hypotheses must not crash and must match wherever the oracle is finite."""
+    rng = np.random.default_rng(31)
+    B, C, G, h, w = 2, 32, 16, 8, 16
+    ref = smooth_field(rng, (B, C, h, w), 2, -1, 1)
+    src = smooth_field(rng, (B, C, h, w), 2, -1, 1)
+    K, invK = kitti_K(h, w, B)
+    pose = rand_pose(oracle_lib, rng, B, 0.02, 0.1)
+    hyp1 = (2 + 20 * rng.random((B, 1, h, w))).astype(np.float32)
+    out = ops.costvol_grouped(dev(ref), dev(src), dev(K), dev(invK), dev(pose), G, depth_priors=dev(hyp1), layout="bdg")
+    assert_close(host(out), oracle_lib.costvol_grouped(ref, src, K, invK, hyp1, pose, G))
+    zbad = np.array([-3.5, -10.0 / 3.0], np.float32)
+    with np.errstate(all="ignore"):
+        hyp = oracle_lib.schedule_depth_range(hyp1, 6, 0.3, zbad, "inverse")
+        exp = oracle_lib.costvol_grouped(ref, src, K, invK, hyp, pose, G)
+    got = host(ops.costvol_grouped(dev(ref), dev(src), dev(K), dev(invK), dev(pose), G, depth_priors=dev(hyp), layout="bdg"))
+    fin = np.isfinite(exp) & np.isfinite(got)
+    assert fin.mean() > 0.4
+    assert_close(got[fin], exp[fin])
+
+
+def test_unsupported_grouping_fails_loudly(ops):
+    from movedepth_amd._lib import MovedepthHipError
+
+    x = torch.zeros(1, 6, 8, 8, device="cuda")
+    K = torch.eye(4, device="cuda")[None]
+    with pytest.raises(MovedepthHipError):
+        ops.costvol_grouped(x, x, K, K, K, 2, depth_priors=torch.ones(1, 2, 8, 8, device="cuda"))  # C/G = 3

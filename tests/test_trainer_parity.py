@@ -192,3 +192,29 @@ def test_eval_path_matches_training_forward_and_checkpoint_roundtrip(tmp_path):
     t.load_model()
     for k, v in t.models["reg3d"].state_dict().items():
         assert torch.equal(v, before[k]), k
+
+
+def test_process_batch_three_lookup_frames_and_flags():
+    """BASELINE config 5 shape of the path: matching_ids [0,-1,1] (two lookup frames -> the fusion kernel runs) in
+    the velocity-guided phase, with the optional MVS masks / smoothness switched on.  The reference cannot run this
+    (App. B-8); here the first lookup frame's z drives the range.  Checks finiteness and gradients."""
+    from movedepth_amd.options import MovedepthOptions
+    from movedepth_amd.synthetic import make_inputs
+    from movedepth_amd.trainer import Trainer
+
+    opt = MovedepthOptions().parse(["--height", "64", "--width", "128", "--num_depth_bins", "8", "--batch_size", "2",
+                                    "--matching_ids", "0", "-1", "1", "--mask_mvs_auto", "--mask_mvs_dist", "--mask_mvs_conf",
+                                    "--mvs_smooth_loss", "--weights_init", "scratch", "--miopen_find", "0"])
+    torch.manual_seed(2)
+    np.random.seed(2)
+    t = Trainer(opt)
+    t.epoch = opt.ztrans_start_epc + 1
+    t.set_train()
+    inputs = make_inputs(2, 64, 128, opt.frame_ids, seed=1, device=t.device)
+    outputs, losses = t.train_step(inputs)
+    assert torch.isfinite(losses["loss"].detach())
+    assert "photo_conf_map" in outputs and "dist_mask" in outputs and "mvs_smooth_loss/0" in losses
+    assert outputs["depth_mvs"].shape == (2, 64, 128)  # bilinear upsample path (no --convex_up)
+    for name, m in t.models.items():
+        for pn, p in m.named_parameters():
+            assert p.grad is not None and torch.isfinite(p.grad).all(), (name, pn)
