@@ -643,8 +643,7 @@ int launch(const CvPtrs &q, CvDims dm, hipStream_t stream) {
         return MD_EINVAL;
     }
     const int CPW = GS * N;
-    const int tw_env = env_int("MD_COSTVOL_TW", 0);
-    const int TW = tw_env == 64 ? 64 : 32;
+    constexpr int TW = 32;  // 64-wide tiles measured slower at every setting (w=160 wastes 17 % of the lanes)
     const int TH = 256 / TW;
     dm.tiles_x = md_cdiv(dm.w, TW);
     const int tiles = dm.tiles_x * md_cdiv(dm.h, TH);
@@ -701,11 +700,7 @@ int launch(const CvPtrs &q, CvDims dm, hipStream_t stream) {
         if (q.hyp) MD_CV_LAUNCH(GS_, N_, TW_, false); \
         else MD_CV_LAUNCH(GS_, N_, TW_, true);       \
     } while (0)
-#define MD_CV_TW(GS_, N_)                  \
-    do {                                   \
-        if (TW == 64) MD_CV_F(GS_, N_, 64); \
-        else MD_CV_F(GS_, N_, 32);         \
-    } while (0)
+#define MD_CV_TW(GS_, N_) MD_CV_F(GS_, N_, 32)
 
     bool launched = true;
     switch (N * 100 + CPW) {
