@@ -208,10 +208,10 @@ __device__ __forceinline__ vecf<CPW> sample_window(const float4 *win, const Tap4
 
 // In-window fast path: bilinear samples of all CPW channels from the LDS window, multiplied by the ref features
 // (1/N folded in) and summed per group.  og[j] = group j's output.
-template <int GS, int N, int TW>
+template <int GS, int N, int WW_, int WP_>
 __device__ __forceinline__ void groups_from_window(const float4 *wp, const Tap4 &t, const vecf<GS * N> &rf, float (&og)[GS]) {
     constexpr int CPW = GS * N, QPP = CPW / 4;
-    using T = Tile<TW, CPW>;
+    struct T { enum { WW = WW_, WP = WP_ }; };
     using SL = Slots<GS, N>;
     const v2f w00 = t.w00, w01 = t.w01, w10 = t.w10, w11 = t.w11;  // broadcast pairs -> v_pk_fma_f32
     if (SL::QUADMAP) {
@@ -407,7 +407,7 @@ __global__ __launch_bounds__(256) void costvol_fwd_kernel(const float *__restric
         const int lx = t.x0 - ox, ly = t.y0 - oy;
         float og[GS];
         if ((unsigned)lx < (unsigned)(T::WW - 1) && (unsigned)ly < (unsigned)(T::WH - 1))
-            groups_from_window<GS, N, TW>(win + ly * T::WW + lx, t, rf, og);
+            groups_from_window<GS, N, T::WW, T::WP>(win + ly * T::WW + lx, t, rf, og);
         else
             groups_from_global<GS, N>(srcb, dm.h, dm.w, dm.G, gbase, t, rf, og);
 #pragma unroll
@@ -485,7 +485,7 @@ __global__ __launch_bounds__(256) void costvol_fwd_nhwc_kernel(const float *__re
             const Tap4 t = wk.tap_at(dep);
             const int lx = t.x0 - ox, ly = t.y0 - oy;
             if ((unsigned)lx < (unsigned)(T::WW - 1) && (unsigned)ly < (unsigned)(T::WH - 1))
-                groups_from_window<GS, N, TW>(win + ly * T::WW + lx, t, rf, og);
+                groups_from_window<GS, N, T::WW, T::WP>(win + ly * T::WW + lx, t, rf, og);
             else
                 groups_from_global<GS, N>(srcb, dm.h, dm.w, dm.G, gbase, t, rf, og);
         } else {
