@@ -652,7 +652,8 @@ int launch(const CvPtrs &q, CvDims dm, hipStream_t stream) {
     // workgroup each, with dsplit the largest divisor of D that keeps all workgroups resident at once (slots =
     // 256 CUs x workgroups per CU by LDS, <= 8 by waves) and leaves >= 8 hypotheses per slice.  Measured at
     // B=6, 48x160, D=96: slices that straddle two items (a perfectly balanced linear split) cost more in window
-    // re-staging than the balance wins (72 vs 60 us), so slices never cross items unless MD_COSTVOL_NWG forces it.
+    // re-staging than the balance wins (72 vs 60 us), so slices never cross items unless MD_COSTVOL_NWG forces it
+    // (exception: the channels-last forward, below).
     dm.tiles = tiles;
     dm.splits = splits;
     dm.items = dm.B * tiles * splits;
@@ -674,6 +675,12 @@ int launch(const CvPtrs &q, CvDims dm, hipStream_t stream) {
         }
         while (dm.D % dsplit != 0) --dsplit;
         nwg = (long long)dm.items * dsplit;
+        // Channels-last forward only: LDS allows 2 workgroups per CU, and item-aligned slices rarely fill the slots
+        // evenly (B=6, 48x160: 360 workgroups on 512 slots, so 104 CUs carry two and 152 carry one).  A linear
+        // split over exactly `slots` workgroups measured 70.2 us against 74.5 us (medians of 8 interleaved runs,
+        // 7 of 8 pairs faster) despite ~1/3 of the workgroups staging two windows.  The planar kernels measured
+        // the opposite (72 vs 60 us) and keep item-aligned slices.
+        if (cl_out && nwg < slots && total >= slots * 8 && env_int("MD_COSTVOL_CL_FILL", 1)) nwg = slots;
     }
     if (nwg > total) nwg = total;
     if (nwg * ITV_MAX < total) nwg = (total + ITV_MAX - 1) / ITV_MAX;  // a share fits the interval table
