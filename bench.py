@@ -89,6 +89,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch_per_gpu", type=int, default=6)
     ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--trainer_args", default="", help="extra movedepth_amd options, e.g. '--hip_prob_conv 0' for an A/B")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -122,6 +123,7 @@ def main():
     argv = ["--height", "192", "--width", "640", "--num_depth_bins", "96", "--batch_size", str(a.batch_per_gpu),
             "--res_arch", "18", "--prior_scale", "2", "--convex_up", "--weights_init", "scratch", "--learning_rate", "2e-4",
             "--local_rank", str(local_rank)]
+    argv += a.trainer_args.split()
     if world > 1:
         argv.append("--ddp")
     share_gpu = os.environ.get("MD_SHARE_GPU", "0") == "1"

@@ -154,6 +154,21 @@ int md_convex_upsample_fwd(const float *depth, const float *mask, int B, int h, 
 int md_convex_upsample_bwd(const float *gout, const float *depth, const float *mask, int B, int h, int w, int scale,
                            float *d_depth, float *d_mask, md_stream_t stream);
 
+/* ---- reg3d's last layer, the producer of the logits above (the 3-D conv hand-off) ------------
+ * `prob = nn.Conv3d(base_channels, 1, 3, stride=1, padding=1, bias=False)` (networks/resnet_encoder.py:254,
+ * applied :277): 3x3x3, zero padding, ONE output channel.
+ * x, dx: channels-last volume [B,D,H,W,C] (torch channels_last_3d storage of a [B,C,D,H,W] tensor), C in {8,16};
+ * y, gy: [B,D,H,W] (= [B,1,D,H,W]); weight element (tap k = (kd*3+kh)*3+kw, channel c) at
+ * wt[k*w_stride_k + c*w_stride_c]  (contiguous [1,C,3,3,3]: 1, 27; channels_last_3d: C, 1); dwt likewise.
+ * ws: md_conv3d_c1_bwd_weight_ws_bytes() bytes (one partial per workgroup, summed in a fixed order). */
+int md_conv3d_c1_fwd(const float *x, const float *wt, long long w_stride_k, long long w_stride_c, float *y, int B,
+                     int C, int D, int H, int W, md_stream_t stream);
+int md_conv3d_c1_bwd_data(const float *gy, const float *wt, long long w_stride_k, long long w_stride_c, float *dx,
+                          int B, int C, int D, int H, int W, md_stream_t stream);
+size_t md_conv3d_c1_bwd_weight_ws_bytes(int B, int C, int D, int H, int W);
+int md_conv3d_c1_bwd_weight(const float *x, const float *gy, float *dwt, long long dw_stride_k, long long dw_stride_c,
+                            void *ws, size_t ws_bytes, int B, int C, int D, int H, int W, md_stream_t stream);
+
 /* ---- standalone geometry, for call compatibility (the hot kernels fuse these; forward only) -------
  * BackprojectDepth.forward (layers.py:581-586): depth [Bs,h*w], invK [nk,4,4] (nk = 1 or Bs) -> cam_points [Bs,4,h*w].
  * Project3D.forward (layers.py:601-621): points [Bs,4,h*w], K, T [nk,4,4] -> pix [Bs,h,w,2] in [-1,1]. */

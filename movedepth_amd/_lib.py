@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmovedepth_hip.so")
+LIB_PATH = os.environ.get("MOVEDEPTH_HIP_LIB") or os.path.join(_HERE, "libmovedepth_hip.so")  # override: kernel A/B builds
 
 _vp = ctypes.c_void_p
 _i = ctypes.c_int
@@ -44,6 +44,10 @@ SIGNATURES = {
     "md_softmax_entropy_localmax_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "md_convex_upsample_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "md_convex_upsample_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "md_conv3d_c1_fwd": (_i, [_vp, _vp, _ll, _ll, _vp, _i, _i, _i, _i, _i, _vp]),
+    "md_conv3d_c1_bwd_data": (_i, [_vp, _vp, _ll, _ll, _vp, _i, _i, _i, _i, _i, _vp]),
+    "md_conv3d_c1_bwd_weight_ws_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "md_conv3d_c1_bwd_weight": (_i, [_vp, _vp, _vp, _ll, _ll, _vp, _sz, _i, _i, _i, _i, _i, _vp]),
     "md_backproject": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "md_project3d": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp]),
 }

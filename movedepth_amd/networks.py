@@ -14,6 +14,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import ops
+
 
 # --------------------------------------------------------------------------- ResNet (torchvision-compatible keys)
 class _BasicBlock(nn.Module):
@@ -339,6 +341,7 @@ class reg3d(nn.Module):
     # compilation.  torch reads the benchmark flag when a conv (or its backward) executes, so it is switched on
     # around the forward and, through tensor hooks, around this module's part of the backward pass.
     find_convs = True
+    hip_prob = True   # False: keep `prob` on the library convolution too (used by the A/B in tools/ and tests)
 
     def forward(self, inputs):
         if not self.find_convs or not inputs.is_cuda:
@@ -374,6 +377,11 @@ class reg3d(nn.Module):
         else:
             x = c2
         x = c0 + self.conv11(x)
+        # last layer (C -> 1): hand-written kernels instead of the library's GEMM-shaped ones (1177 / 285 / 2568 us
+        # fwd / bwd-data / bwd-weight at 6x16x96x48x160 against ~50 us of memory traffic each); other channel counts
+        # and the NCDHW mode stay with the library convolution
+        if cl and x.is_cuda and x.shape[1] in ops.CONV3D_C1_CHANNELS and self.hip_prob:
+            return ops.conv3d_c1(x, self.prob.weight).squeeze(1)
         return self.prob(x).squeeze(1)
 
 
@@ -403,6 +411,11 @@ class reg2d(nn.Module):
         x = c4 + self.conv7(self.conv6(self.conv5(c4)))
         x = c2 + self.conv9(x)
         x = c0 + self.conv11(x)
+        # last layer (C -> 1): hand-written kernels instead of the library's GEMM-shaped ones (1177 / 285 / 2568 us
+        # fwd / bwd-data / bwd-weight at 6x16x96x48x160 against ~50 us of memory traffic each); other channel counts
+        # and the NCDHW mode stay with the library convolution
+        if cl and x.is_cuda and x.shape[1] in ops.CONV3D_C1_CHANNELS and self.hip_prob:
+            return ops.conv3d_c1(x, self.prob.weight).squeeze(1)
         return self.prob(x).squeeze(1)
 
 

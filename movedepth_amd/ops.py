@@ -448,6 +448,61 @@ def convex_upsample(depth, mask, scale=2):
     return _ConvexUpsample.apply(depth, mask, scale)
 
 
+# --------------------------------------------------------------------------- reg3d's last layer (one output channel)
+CONV3D_C1_CHANNELS = (8, 16)
+
+
+def _c1_weight_strides(w):
+    """(tap stride, channel stride) of a [1,C,3,3,3] weight whose 27 taps are evenly spaced in memory."""
+    s = w.stride()
+    if s[3] != 3 * s[4] or s[2] != 9 * s[4]:
+        raise _lib.MovedepthHipError("conv3d_c1: weight strides %s are not tap-regular" % (tuple(s),))
+    return s[4], s[1]
+
+
+class _Conv3dC1(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight):
+        if not x.is_cuda:
+            raise _lib.MovedepthHipError("conv3d_c1: x must be a GPU tensor (got %s)" % x.device)
+        B, C, D, H, W = x.shape
+        if tuple(weight.shape) != (1, C, 3, 3, 3):
+            raise _lib.MovedepthHipError("conv3d_c1: weight %s does not match x %s" % (tuple(weight.shape), tuple(x.shape)))
+        x = x.float().contiguous(memory_format=torch.channels_last_3d)      # no copy when already NDHWC
+        weight = weight.float()
+        wsk, wsc = _c1_weight_strides(weight)
+        y = torch.empty(B, 1, D, H, W, device=x.device, dtype=torch.float32)
+        _timed_call("md_conv3d_c1_fwd", _p(x), _p(weight), wsk, wsc, _p(y), B, C, D, H, W, _stream())
+        ctx.save_for_backward(x, weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        B, C, D, H, W = x.shape
+        gy = gy.float().contiguous()
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            wsk, wsc = _c1_weight_strides(weight)
+            dx = torch.empty_like(x, memory_format=torch.channels_last_3d)
+            _timed_call("md_conv3d_c1_bwd_data", _p(gy), _p(weight), wsk, wsc, _p(dx), B, C, D, H, W, _stream())
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(weight)                                   # preserves the weight's strides
+            dsk, dsc = _c1_weight_strides(dw)
+            nbytes = _lib.load().md_conv3d_c1_bwd_weight_ws_bytes(B, C, D, H, W)
+            ws = _ws(nbytes, x.device)
+            _timed_call("md_conv3d_c1_bwd_weight", _p(x), _p(gy), _p(dw), dsk, dsc, _p(ws), int(nbytes), B, C, D, H, W,
+                        _stream())
+        return dx, dw
+
+
+def conv3d_c1(x, weight):
+    """nn.Conv3d(C, 1, 3, stride=1, padding=1, bias=False) -- reg3d.prob, reference networks/resnet_encoder.py:254,277.
+    x (B,C,D,H,W), C in CONV3D_C1_CHANNELS, read as channels_last_3d storage; weight (1,C,3,3,3) in either memory
+    format -> (B,1,D,H,W).  Gradients to x (channels_last_3d) and weight."""
+    return _Conv3dC1.apply(x, weight)
+
+
 def backproject(depth, inv_K, batch_size, height, width):
     """BackprojectDepth.forward (reference layers.py:581-586), forward only -> (Bs,4,h*w)."""
     with torch.no_grad():

@@ -81,6 +81,7 @@ class Trainer:
         # library convolutions: the 3-D regulariser runs channels-last (its input volume is written in that layout by
         # the HIP kernel) with MIOpen's solver search enabled for its convs only (see networks.reg3d)
         self.models["reg3d"].find_convs = bool(opt.miopen_find)
+        self.models["reg3d"].hip_prob = bool(opt.hip_prob_conv)
         self.vol_layout = "bgd"
         if opt.reg3d_channels_last and opt.num_depth_bins >= 8:
             self.models["reg3d"] = self.models["reg3d"].to(memory_format=torch.channels_last_3d)

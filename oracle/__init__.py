@@ -291,3 +291,22 @@ def convex_upsample(depth, mask, scale=2):
     out = np.empty((B, s * h, s * w), np.float32)
     lib().mdo_convex_upsample(_p(depth), _p(mask), _i(B), _i(h), _i(w), _i(scale), _p(out))
     return out
+
+
+def conv3d_c1(x, wt):
+    """reg3d.prob forward: x [B,C,D,H,W], wt [1,C,3,3,3] -> [B,1,D,H,W]  (resnet_encoder.py:254,277)"""
+    x, wt = _c(x), _c(wt)
+    B, C, D, H, W = x.shape
+    assert wt.shape == (1, C, 3, 3, 3)
+    y = np.empty((B, 1, D, H, W), np.float32)
+    lib().mdo_conv3d_c1_fwd(_p(x), _p(wt), _i(B), _i(C), _i(D), _i(H), _i(W), _p(y))
+    return y
+
+
+def conv3d_c1_bwd(gy, x, wt):
+    """adjoint of conv3d_c1: returns (dx [B,C,D,H,W], dwt [1,C,3,3,3])"""
+    gy, x, wt = _c(gy), _c(x), _c(wt)
+    B, C, D, H, W = x.shape
+    dx, dwt = np.empty_like(x), np.empty_like(wt)
+    lib().mdo_conv3d_c1_bwd(_p(gy), _p(x), _p(wt), _i(B), _i(C), _i(D), _i(H), _i(W), _p(dx), _p(dwt))
+    return dx, dwt

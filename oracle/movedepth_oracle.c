@@ -881,3 +881,87 @@ void mdo_convex_upsample(const float *depth, const float *mask, int B, int h, in
                         out[((size_t)b * s * h + (y * s + i)) * ((size_t)s * w) + x * s + j] = acc;
                     }
 }
+
+/* reg3d's last layer `prob`: nn.Conv3d(base_channels, 1, 3, stride=1, padding=1, bias=False)
+ * (networks/resnet_encoder.py:254, applied :277).  Plain NCDHW indexing as the reference sees it:
+ * x [B,C,D,H,W]; wt [1,C,3,3,3]; y [B,1,D,H,W].  fp64 accumulation (this is the checker, not the product). */
+void mdo_conv3d_c1_fwd(const float *x, const float *wt, int B, int C, int D, int H, int W, float *y) {
+    size_t hw = (size_t)H * W, dhw = (size_t)D * hw;
+#pragma omp parallel for collapse(2)
+    for (int b = 0; b < B; ++b)
+        for (int d = 0; d < D; ++d)
+            for (int h = 0; h < H; ++h)
+                for (int w = 0; w < W; ++w) {
+                    double acc = 0.0;
+                    for (int c = 0; c < C; ++c)
+                        for (int kd = 0; kd < 3; ++kd) {
+                            int dd = d + kd - 1;
+                            if (dd < 0 || dd >= D) continue;
+                            for (int kh = 0; kh < 3; ++kh) {
+                                int hh = h + kh - 1;
+                                if (hh < 0 || hh >= H) continue;
+                                for (int kw = 0; kw < 3; ++kw) {
+                                    int ww = w + kw - 1;
+                                    if (ww < 0 || ww >= W) continue;
+                                    acc += (double)x[((size_t)b * C + c) * dhw + dd * hw + (size_t)hh * W + ww] *
+                                           (double)wt[c * 27 + (kd * 3 + kh) * 3 + kw];
+                                }
+                            }
+                        }
+                    y[(size_t)b * dhw + d * hw + (size_t)h * W + w] = (float)acc;
+                }
+}
+
+/* Adjoint of the above: gy [B,1,D,H,W] -> dx [B,C,D,H,W] and dwt [1,C,3,3,3] (either may be NULL). */
+void mdo_conv3d_c1_bwd(const float *gy, const float *x, const float *wt, int B, int C, int D, int H, int W, float *dx,
+                       float *dwt) {
+    size_t hw = (size_t)H * W, dhw = (size_t)D * hw;
+    if (dx) {
+#pragma omp parallel for collapse(2)
+        for (int b = 0; b < B; ++b)
+            for (int c = 0; c < C; ++c)
+                for (int d = 0; d < D; ++d)
+                    for (int h = 0; h < H; ++h)
+                        for (int w = 0; w < W; ++w) {
+                            double acc = 0.0;
+                            for (int kd = 0; kd < 3; ++kd) {
+                                int dd = d - kd + 1; /* output voxel that read x[d] through tap kd */
+                                if (dd < 0 || dd >= D) continue;
+                                for (int kh = 0; kh < 3; ++kh) {
+                                    int hh = h - kh + 1;
+                                    if (hh < 0 || hh >= H) continue;
+                                    for (int kw = 0; kw < 3; ++kw) {
+                                        int ww = w - kw + 1;
+                                        if (ww < 0 || ww >= W) continue;
+                                        acc += (double)gy[(size_t)b * dhw + dd * hw + (size_t)hh * W + ww] *
+                                               (double)wt[c * 27 + (kd * 3 + kh) * 3 + kw];
+                                    }
+                                }
+                            }
+                            dx[((size_t)b * C + c) * dhw + d * hw + (size_t)h * W + w] = (float)acc;
+                        }
+    }
+    if (dwt) {
+#pragma omp parallel for
+        for (int o = 0; o < C * 27; ++o) {
+            int c = o / 27, k = o % 27, kd = k / 9, kh = (k / 3) % 3, kw = k % 3;
+            double acc = 0.0;
+            for (int b = 0; b < B; ++b)
+                for (int d = 0; d < D; ++d) {
+                    int dd = d + kd - 1;
+                    if (dd < 0 || dd >= D) continue;
+                    for (int h = 0; h < H; ++h) {
+                        int hh = h + kh - 1;
+                        if (hh < 0 || hh >= H) continue;
+                        for (int w = 0; w < W; ++w) {
+                            int ww = w + kw - 1;
+                            if (ww < 0 || ww >= W) continue;
+                            acc += (double)x[((size_t)b * C + c) * dhw + dd * hw + (size_t)hh * W + ww] *
+                                   (double)gy[(size_t)b * dhw + d * hw + (size_t)h * W + w];
+                        }
+                    }
+                }
+            dwt[o] = (float)acc;
+        }
+    }
+}

@@ -428,3 +428,98 @@ def test_unsupported_grouping_fails_loudly(ops):
     K = torch.eye(4, device="cuda")[None]
     with pytest.raises(MovedepthHipError):
         ops.costvol_grouped(x, x, K, K, K, 2, depth_priors=torch.ones(1, 2, 8, 8, device="cuda"))  # C/G = 3
+
+
+# ------------------------------------------------------------------ reg3d's last layer (C -> 1 convolution)
+def _cl3d(t):
+    return t.contiguous(memory_format=torch.channels_last_3d)
+
+
+@pytest.mark.parametrize("weight_cl", [False, True])
+@pytest.mark.parametrize("tag", ["c16", "c8"])
+def test_prob_conv_golden(ops, tag, weight_cl):
+    g = load_golden("prob_conv_" + tag)
+    x = _cl3d(dev(g["x"])).requires_grad_(True)
+    w = dev(g["weight"])
+    w = (_cl3d(w) if weight_cl else w).requires_grad_(True)
+    y = ops.conv3d_c1(x, w)
+    assert y.shape == (x.shape[0], 1) + tuple(x.shape[2:])
+    assert_close(host(y)[:, 0], g["y"], what="prob y")
+    (y[:, 0] * dev(g["grad_out"])).sum().backward()
+    assert x.grad.is_contiguous(memory_format=torch.channels_last_3d) and w.grad.stride() == w.stride()
+    assert_close(host(x.grad), g["d_x"], what="prob d_x")
+    assert_close(host(w.grad), g["d_weight"], what="prob d_weight")
+
+
+@pytest.mark.parametrize("shape", [
+    (2, 16, 19, 13, 45),    # ragged everywhere; D=19 -> 2 slices of 10 and 9 planes
+    (1, 16, 40, 8, 32),     # exactly one tile, 4 slices: every slice boundary inside the volume
+    (1, 8, 17, 20, 70),     # 8 channels (2 quads per voxel), 3x3 tiles
+    (3, 16, 1, 5, 3),       # a single plane, smaller than the halo
+    (1, 16, 2, 1, 1),       # one voxel column
+])
+def test_prob_conv_vs_oracle(ops, oracle_lib, shape):
+    rng = np.random.default_rng(21)
+    B, C, D, H, W = shape
+    x = rng.standard_normal(shape).astype(np.float32)
+    wt = (rng.standard_normal((1, C, 3, 3, 3)) * 0.1).astype(np.float32)
+    gy = rng.standard_normal((B, 1, D, H, W)).astype(np.float32)
+    exp = oracle_lib.conv3d_c1(x, wt)
+    exp_dx, exp_dw = oracle_lib.conv3d_c1_bwd(gy, x, wt)
+    xt, wtt = _cl3d(dev(x)).requires_grad_(True), dev(wt, True)
+    y = ops.conv3d_c1(xt, wtt)
+    assert_close(host(y), exp, what="y")
+    (y * dev(gy)).sum().backward()
+    assert_close(host(xt.grad), exp_dx, what="d_x")
+    assert_close(host(wtt.grad), exp_dw, what="d_weight")
+
+
+def test_prob_conv_full_size_vs_library(ops):
+    """BASELINE config 2 size (6x16x96x48x160): against the library convolution on the same device (the CPU oracle
+    would take minutes), plus linearity in x (a size-independent property) and determinism of the weight gradient."""
+    torch.manual_seed(5)
+    B, C, D, H, W = 6, 16, 96, 48, 160
+    x = _cl3d(torch.randn(B, C, D, H, W, device="cuda")).requires_grad_(True)
+    w = (torch.randn(1, C, 3, 3, 3, device="cuda") * 0.1).requires_grad_(True)
+    gy = torch.randn(B, 1, D, H, W, device="cuda")
+    y = ops.conv3d_c1(x, w)
+    dx, dw = torch.autograd.grad(y, (x, w), gy)
+    x2, w2 = x.detach().clone().requires_grad_(True), w.detach().clone().requires_grad_(True)
+    y_ref = torch.nn.functional.conv3d(x2, w2, padding=1)
+    dx_ref, dw_ref = torch.autograd.grad(y_ref, (x2, w2), gy)
+    assert_close(host(y), host(y_ref), what="y")
+    assert_close(host(dx), host(dx_ref), what="d_x")
+    assert_close(host(dw), host(dw_ref), what="d_weight")
+    with torch.no_grad():
+        x3 = _cl3d(torch.randn_like(x))
+        lin = ops.conv3d_c1(x.detach() + 0.5 * x3, w.detach())
+        assert_close(host(lin), host(y.detach() + 0.5 * ops.conv3d_c1(x3, w.detach())), what="linearity")
+    dw_again = torch.autograd.grad(ops.conv3d_c1(x, w), w, gy)[0]
+    assert torch.equal(dw, dw_again), "weight gradient must be bit-reproducible (fixed-order reduction)"
+
+
+def test_prob_conv_rejects_unsupported(ops):
+    from movedepth_amd._lib import MovedepthHipError
+    x = _cl3d(torch.randn(1, 12, 4, 4, 4, device="cuda"))
+    with pytest.raises(MovedepthHipError):
+        ops.conv3d_c1(x, torch.randn(1, 12, 3, 3, 3, device="cuda"))
+    with pytest.raises(MovedepthHipError):
+        ops.conv3d_c1(torch.randn(1, 16, 4, 4, 4), torch.randn(1, 16, 3, 3, 3))
+
+
+def test_reg3d_prob_paths_agree(ops):
+    """reg3d with the hand-written last layer against the same module with the library convolution."""
+    from movedepth_amd import networks
+    torch.manual_seed(3)
+    net = networks.reg3d(16, 16, 3).cuda().to(memory_format=torch.channels_last_3d)
+    vol = torch.randn(2, 16, 16, 24, 32, device="cuda")  # (B,D,G,h,w)
+    outs = []
+    for hip in (True, False):
+        net.hip_prob = hip
+        net.zero_grad()
+        v = vol.clone().requires_grad_(True)
+        o = net(v)
+        o.square().mean().backward()
+        outs.append((host(o), host(v.grad), host(net.prob.weight.grad)))
+    for a, b, what in zip(outs[0], outs[1], ("logits", "d_volume", "d_prob_weight")):
+        assert_close(a, b, what=what)

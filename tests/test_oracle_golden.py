@@ -172,3 +172,13 @@ def test_postvol(oracle_lib):
     assert_close(out, g["kat_onehot_depth"], rtol=1e-5)
     assert_close(out[0, 0], kh[0, ::-1, 0, 0], rtol=1e-4)
     assert_close(oracle_lib.convex_upsample(g["up_depth"], g["up_mask"], 2), g["up_out"], rtol=1e-5)
+
+
+@pytest.mark.parametrize("tag", ["c16", "c8"])
+def test_prob_conv(oracle_lib, tag):
+    """reg3d's last layer (resnet_encoder.py:254,277) through the reference's own module, incl. both gradients."""
+    g = load_golden("prob_conv_" + tag)
+    assert_close(oracle_lib.conv3d_c1(g["x"], g["weight"])[:, 0], g["y"], rtol=1e-5, what="prob y")
+    dx, dw = oracle_lib.conv3d_c1_bwd(g["grad_out"][:, None], g["x"], g["weight"])
+    assert_close(dx, g["d_x"], rtol=1e-5, what="prob d_x")
+    assert_close(dw, g["d_weight"], rtol=1e-5, what="prob d_weight")

@@ -1,0 +1,40 @@
+"""GPU: the hand-written C->1 convolution (reg3d.prob) against the library convolution, per direction, at the
+BASELINE config-2 volume.  Bytes are algorithmic: fwd reads x + writes y; bwd-data reads gy + writes dx;
+bwd-weight reads x + gy."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from movedepth_amd import ops
+
+torch.backends.cudnn.benchmark = True
+B, C, D, H, W = 6, int(os.environ.get("C", 16)), 96, 48, 160
+x = torch.randn(B, C, D, H, W, device="cuda").contiguous(memory_format=torch.channels_last_3d)
+w = (torch.randn(1, C, 3, 3, 3, device="cuda") * 0.1).contiguous(memory_format=torch.channels_last_3d)
+gy = torch.randn(B, 1, D, H, W, device="cuda")
+xb, yb = x.numel() * 4, gy.numel() * 4
+
+
+def ev(fn, n=20, warm=3):
+    for _ in range(warm):
+        fn()
+    s, e = torch.cuda.Event(True), torch.cuda.Event(True)
+    s.record()
+    for _ in range(n):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / n * 1e3
+
+
+xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+yh = ops.conv3d_c1(xr, wr)
+mask = lambda m: torch.ops.aten.convolution_backward(gy, x, w, None, [1] * 3, [1] * 3, [1] * 3, False, [0] * 3, 1, m)
+rows = [("fwd", lambda: ops.conv3d_c1(x, w), lambda: torch.nn.functional.conv3d(x, w, padding=1), xb + yb),
+        ("bwd-data", lambda: torch.autograd.grad(yh, xr, gy, retain_graph=True), lambda: mask([True, False, False]), xb + yb),
+        ("bwd-weight", lambda: torch.autograd.grad(yh, wr, gy, retain_graph=True), lambda: mask([False, True, False]), xb + yb)]
+skip_lib = os.environ.get("NO_LIB") == "1"
+print("conv3d_c1 B=%d C=%d %dx%dx%d  lib=%s" % (B, C, D, H, W, os.environ.get("MOVEDEPTH_HIP_LIB", "default")))
+for name, mine, lib, nbytes in rows:
+    t = ev(mine)
+    tl = float("nan") if skip_lib else ev(lib, n=5, warm=2)
+    print("  %-10s %8.1f us  %6.0f GB/s (%4.1f%% of 8 TB/s)   library %8.1f us" % (name, t, nbytes / t * 1e-3, nbytes / t * 1e-3 / 80, tl), flush=True)

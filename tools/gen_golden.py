@@ -382,9 +382,26 @@ def gen_postvol(L):
                          d_up_mask=mask.grad))
 
 
+def gen_prob_conv(networks):
+    """reg3d's last layer through the reference's own module (networks/resnet_encoder.py:254, applied :277):
+    prob(x).squeeze(1) on the tensor the U-Net hands it, with gradients to that tensor and to the weight.
+    Ragged sizes (not multiples of the kernel's 8x32 tile, D not a multiple of its slices)."""
+    g = torch.Generator().manual_seed(811)
+    for tag, (B, C, D, H, W) in (("c16", (2, 16, 11, 10, 37)), ("c8", (1, 8, 5, 9, 33))):
+        torch.manual_seed(812)
+        net = networks.reg3d(C, C, down_size=1)
+        x = torch.randn(B, C, D, H, W, generator=g).requires_grad_(True)
+        y = net.prob(x).squeeze(1)
+        Wy = torch.randn(y.shape, generator=g)
+        (y * Wy).sum().backward()
+        save("prob_conv_" + tag, dict(x=x, weight=net.prob.weight, y=y, grad_out=Wy, d_x=x.grad,
+                                      d_weight=net.prob.weight.grad))
+
+
 def main():
     torch.set_num_threads(1)
-    L, Trainer, _ = load_reference(with_trainer=True)
+    L, Trainer, networks = load_reference(with_trainer=True)
+    gen_prob_conv(networks)
     gen_geometry(L)
     gen_schedule(L)
     gen_costvol(L)
