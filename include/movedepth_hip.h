@@ -169,6 +169,17 @@ size_t md_conv3d_c1_bwd_weight_ws_bytes(int B, int C, int D, int H, int W);
 int md_conv3d_c1_bwd_weight(const float *x, const float *gy, float *dwt, long long dw_stride_k, long long dw_stride_c,
                             void *ws, size_t ws_bytes, int B, int C, int D, int H, int W, md_stream_t stream);
 
+/* ---- reg3d's first layer, the consumer of the grouped cost volume: weight gradient -----------------------
+ * `conv0.conv = nn.Conv3d(16, 16, 3, stride=1, padding=1, bias=False)` (networks/resnet_encoder.py:231 through
+ * ConvBnReLU3D, applied :258).  x, gy: channels-last volumes [B,D,H,W,16]; dwt element (co, ci, tap k) at
+ * dwt[co*dw_stride_co + ci*dw_stride_ci + k*dw_stride_k] (contiguous [16,16,3,3,3]: 432, 27, 1;
+ * channels_last_3d: 432, 1, 16).  Ci == Co == 16 only (MD_EINVAL otherwise).  fp32 MFMA, fixed-order reduction.
+ * The forward and the data gradient of this layer stay with the library convolution. */
+size_t md_conv3d_c16_bwd_weight_ws_bytes(int B, int D, int H, int W);
+int md_conv3d_c16_bwd_weight(const float *x, const float *gy, float *dwt, long long dw_stride_co, long long dw_stride_ci,
+                             long long dw_stride_k, void *ws, size_t ws_bytes, int B, int Ci, int Co, int D, int H, int W,
+                             md_stream_t stream);
+
 /* ---- standalone geometry, for call compatibility (the hot kernels fuse these; forward only) -------
  * BackprojectDepth.forward (layers.py:581-586): depth [Bs,h*w], invK [nk,4,4] (nk = 1 or Bs) -> cam_points [Bs,4,h*w].
  * Project3D.forward (layers.py:601-621): points [Bs,4,h*w], K, T [nk,4,4] -> pix [Bs,h,w,2] in [-1,1]. */

@@ -1,0 +1,204 @@
+// 3x3x3, stride 1, pad 1, bias-free 16 -> 16 channel convolution over channels-last (NDHWC) volumes: reg3d's first
+// layer conv0 (reference networks/resnet_encoder.py:231, applied :258), the consumer of the grouped cost volume
+// (G = 16 groups = its 16 input channels).  This file: the weight gradient, which is where the library is weakest
+// (3112 us for 61 GFLOP = 19.7 TF/s at 6x16x96x48x160, profiles/r01_reg3d_layers_miopen.txt).
+//
+//   dwt[co,ci,kd,kh,kw] = sum_{b,d,h,w} x[b,d+kd-1,h+kh-1,w+kw-1,ci] * gy[b,d,h,w,co]
+//
+// MFMA mapping (v_mfma_f32_16x16x4_f32, exact fp32, 157 TF/s peak = the bound of this kernel): for one tap,
+// D[ci][co] += sum over 4 voxels of A[ci][v] * B[v][co] with A = x at the tap-shifted voxels, B = gy.  Both operands
+// are ONE dword per lane in exactly the order the channels-last volumes have in memory (lane = voxel*16 + channel,
+// 4 consecutive voxels along w = 256 contiguous bytes), so gy goes global -> register -> MFMA and x goes
+// LDS -> register -> MFMA with no shuffles.  Each wave keeps all 27 taps' 16x16 accumulators (108 registers).
+// A workgroup owns an 8x32 (h,w) column of one sample and marches over a slice of D with a ring of three x planes
+// (+1 halo, zero-filled outside the image = the zero padding) in LDS; per plane a wave does 16 voxel groups x 27
+// MFMAs.  The 4 waves are summed through LDS, one partial [27][16][16] per workgroup goes to the caller's workspace
+// and a second kernel adds the partials in a fixed order in fp64 (deterministic; no float atomics).
+#include "md_common.hpp"
+
+namespace {
+
+constexpr int TH = 8, TW = 32, HW_ = TW + 2, HH_ = TH + 2, CELLS = HH_ * HW_;
+constexpr int CI = 16, CO = 16, NTAP = 27;
+constexpr int PLANE_F = CELLS * CI;              // floats per staged plane
+constexpr int NLD = (CELLS * 4 + 255) / 256;     // float4 pieces per thread per plane
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct C16Dims {
+    int B, D, H, W;
+    int tiles_x, tiles, dslices, planes;
+};
+
+__device__ __forceinline__ void c16_item(const C16Dims &dm, int item, int &b, int &ty0, int &tx0, int &d0, int &d1) {
+    const int sl = item % dm.dslices;
+    const int t = (item / dm.dslices) % dm.tiles;
+    b = item / (dm.dslices * dm.tiles);
+    tx0 = (t % dm.tiles_x) * TW;
+    ty0 = (t / dm.tiles_x) * TH;
+    d0 = sl * dm.planes;
+    d1 = min(d0 + dm.planes, dm.D);
+}
+
+__global__ __launch_bounds__(256, 2) void conv3d_c16_bwd_weight_kernel(const float *__restrict__ x, const float *__restrict__ gy,
+                                                                      float *__restrict__ partial, const C16Dims dm) {
+    __shared__ float ring[3 * PLANE_F];  // plane P in slot (P + 3) % 3; reused for the wave reduction at the end
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ch = lane & 15, v = lane >> 4;
+    int b, ty0, tx0, d0, d1;
+    c16_item(dm, blockIdx.x, b, ty0, tx0, d0, d1);
+    const size_t plane = (size_t)dm.H * dm.W;
+    const float4 *xb = reinterpret_cast<const float4 *>(x) + (size_t)b * dm.D * plane * 4;
+    const float *gyb = gy + (size_t)b * dm.D * plane * CO;
+
+    // x staging roles: piece idx = cell * 4 + quad, memory order along a tile row
+    int lofs[NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int idx = tid + i * 256, cell = idx >> 2, qq = idx & 3;
+        const int yy = ty0 - 1 + cell / HW_, xx = tx0 - 1 + cell % HW_;
+        lofs[i] = (idx < CELLS * 4 && yy >= 0 && yy < dm.H && xx >= 0 && xx < dm.W) ? (yy * dm.W + xx) * 4 + qq : -1;
+    }
+    float4 pre[NLD];
+    auto fetch = [&](int P) {
+        const bool in = P >= 0 && P < dm.D;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i)
+            pre[i] = (in && lofs[i] >= 0) ? xb[(size_t)P * plane * 4 + lofs[i]] : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    auto stash = [&](int P) {
+        float4 *slot = reinterpret_cast<float4 *>(ring + ((P + 3) % 3) * PLANE_F);
+#pragma unroll
+        for (int i = 0; i < NLD; ++i)
+            if (tid + i * 256 < CELLS * 4) slot[tid + i * 256] = pre[i];
+    };
+    // gy roles: group g of this wave = tile row 2*wave + g/8, columns (g%8)*4 .. +3; lane holds (voxel v, channel ch)
+    auto gy_load = [&](int d, int g) -> float {
+        const int yy = ty0 + 2 * wave + (g >> 3), xx = tx0 + (g & 7) * 4 + v;
+        return (yy < dm.H && xx < dm.W) ? gyb[((size_t)d * plane + (size_t)yy * dm.W + xx) * CO + ch] : 0.f;
+    };
+
+    f32x4 acc[NTAP];
+#pragma unroll
+    for (int k = 0; k < NTAP; ++k) acc[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    fetch(d0 - 1); stash(d0 - 1);
+    fetch(d0);     stash(d0);
+    fetch(d0 + 1);
+    for (int d = d0; d < d1; ++d) {
+        float gcur = gy_load(d, 0);
+        stash(d + 1);
+        __syncthreads();
+        if (d + 1 < d1) fetch(d + 2);
+        const float *s0 = ring + ((d + 2) % 3) * PLANE_F + ch;  // planes d-1, d, d+1
+        const float *s1 = ring + (d % 3) * PLANE_F + ch;
+        const float *s2 = ring + ((d + 1) % 3) * PLANE_F + ch;
+#pragma unroll 1
+        for (int g = 0; g < 16; ++g) {
+            const float gnext = gy_load(d, (g + 1) & 15);  // one group ahead (the wrap-around load is discarded)
+            const int cell = ((2 * wave + (g >> 3)) * HW_ + (g & 7) * 4 + v) * CI;  // this lane's voxel, halo origin
+#pragma unroll
+            for (int kd = 0; kd < 3; ++kd) {
+                const float *sl = (kd == 0 ? s0 : kd == 1 ? s1 : s2) + cell;
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) {
+                        const float a = sl[(kh * HW_ + kw) * CI];
+                        const int k = (kd * 3 + kh) * 3 + kw;
+                        acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, gcur, acc[k], 0, 0, 0);
+                    }
+            }
+            gcur = gnext;
+        }
+        __syncthreads();  // slot (d+2)%3 == (d-1)%3 is rewritten at the top of the next step
+    }
+    // sum the 4 waves through LDS (two waves' accumulators fit at a time), wave 0 writes the workgroup's partial
+    f32x4 *red = reinterpret_cast<f32x4 *>(ring);  // [2][NTAP][64]
+    if (wave >= 2) {
+#pragma unroll
+        for (int k = 0; k < NTAP; ++k) red[((wave - 2) * NTAP + k) * 64 + lane] = acc[k];
+    }
+    __syncthreads();
+    if (wave < 2) {
+#pragma unroll
+        for (int k = 0; k < NTAP; ++k) acc[k] += red[(wave * NTAP + k) * 64 + lane];
+    }
+    __syncthreads();
+    if (wave == 1) {
+#pragma unroll
+        for (int k = 0; k < NTAP; ++k) red[k * 64 + lane] = acc[k];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        f32x4 *out = reinterpret_cast<f32x4 *>(partial) + (size_t)blockIdx.x * NTAP * 64;
+#pragma unroll
+        for (int k = 0; k < NTAP; ++k) out[k * 64 + lane] = acc[k] + red[k * 64 + lane];
+    }
+}
+
+// partial[wg][k][lane][r] holds dW[ci = 4*(lane>>4) + r][co = lane&15] of tap k (the MFMA C/D layout).
+// dwt[co*s_co + ci*s_ci + k*s_k] = sum over workgroups, fixed order, fp64.
+__global__ __launch_bounds__(256) void conv3d_c16_bwd_weight_finish_kernel(const float *__restrict__ partial, int nwg,
+                                                                           long long s_co, long long s_ci, long long s_k,
+                                                                           float *__restrict__ dwt) {
+    __shared__ double sh[4][64];
+    const int ol = threadIdx.x & 63, seg = threadIdx.x >> 6;
+    const int o = blockIdx.x * 64 + ol;  // element of [k][lane][r]
+    double s = 0.0;
+    for (int i = seg; i < nwg; i += 4) s += (double)partial[(size_t)i * (NTAP * 256) + o];
+    sh[seg][ol] = s;
+    __syncthreads();
+    if (seg == 0) {
+        const double t = (sh[0][ol] + sh[1][ol]) + (sh[2][ol] + sh[3][ol]);
+        const int k = o >> 8, lane = (o >> 2) & 63, r = o & 3;
+        const int ci = 4 * (lane >> 4) + r, co = lane & 15;
+        dwt[co * s_co + ci * s_ci + k * s_k] = (float)t;
+    }
+}
+
+int c16_dims(const char *fn, int B, int Ci, int Co, int D, int H, int W, C16Dims &dm) {
+    MD_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0, "%s: bad dims B=%d D=%d H=%d W=%d", fn, B, D, H, W);
+    MD_REQUIRE(Ci == CI && Co == CO, "%s: %d -> %d channels unsupported (16 -> 16 only)", fn, Ci, Co);
+    MD_REQUIRE((long long)D * H * W * CI < (1ll << 31), "%s: one sample must stay below 2^31 elements", fn);
+    dm.B = B; dm.D = D; dm.H = H; dm.W = W;
+    dm.tiles_x = md_cdiv(W, TW);
+    dm.tiles = dm.tiles_x * md_cdiv(H, TH);
+    // two workgroups fit a CU (65 KB of LDS each): at least ~3 per CU in total for balance, >= 8 planes per slice
+    int ds = 1;
+    while (ds * 2 <= D / 8 && (long long)B * dm.tiles * ds < 700) ds *= 2;
+    dm.planes = md_cdiv(D, ds);
+    dm.dslices = md_cdiv(D, dm.planes);
+    return MD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t md_conv3d_c16_bwd_weight_ws_bytes(int B, int D, int H, int W) {
+    C16Dims dm;
+    if (c16_dims("md_conv3d_c16_bwd_weight_ws_bytes", B, CI, CO, D, H, W, dm)) return 0;
+    return (size_t)B * dm.tiles * dm.dslices * NTAP * CI * CO * sizeof(float);
+}
+
+int md_conv3d_c16_bwd_weight(const float *x, const float *gy, float *dwt, long long dw_stride_co, long long dw_stride_ci,
+                             long long dw_stride_k, void *ws, size_t ws_bytes, int B, int Ci, int Co, int D, int H, int W,
+                             md_stream_t stream) {
+    MD_REQUIRE(x && gy && dwt && ws, "md_conv3d_c16_bwd_weight: null tensor argument");
+    MD_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)ws % 16) == 0, "md_conv3d_c16_bwd_weight: x and ws must be 16-byte aligned");
+    C16Dims dm;
+    if (int rc = c16_dims("md_conv3d_c16_bwd_weight", B, Ci, Co, D, H, W, dm)) return rc;
+    const int nwg = B * dm.tiles * dm.dslices;
+    MD_REQUIRE(ws_bytes >= (size_t)nwg * NTAP * CI * CO * sizeof(float), "md_conv3d_c16_bwd_weight: workspace too small (%zu bytes)", ws_bytes);
+    hipStream_t s = (hipStream_t)stream;
+    float *partial = (float *)ws;
+    hipLaunchKernelGGL(conv3d_c16_bwd_weight_kernel, dim3(nwg), dim3(256), 0, s, x, gy, partial, dm);
+    MD_CHECK_LAUNCH("md_conv3d_c16_bwd_weight");
+    hipLaunchKernelGGL(conv3d_c16_bwd_weight_finish_kernel, dim3(NTAP * 256 / 64), dim3(256), 0, s, partial, nwg, dw_stride_co,
+                       dw_stride_ci, dw_stride_k, dwt);
+    MD_CHECK_LAUNCH("md_conv3d_c16_bwd_weight(finish)");
+    return MD_OK;
+}
+
+}  // extern "C"

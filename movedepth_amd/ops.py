@@ -503,6 +503,49 @@ def conv3d_c1(x, weight):
     return _Conv3dC1.apply(x, weight)
 
 
+# --------------------------------------------------------------------------- reg3d's first layer (16 -> 16): weight gradient
+_CONV_ARGS = ([1, 1, 1], [1, 1, 1], [1, 1, 1], False, [0, 0, 0], 1)  # stride, padding, dilation, transposed, out pad, groups
+
+
+class _Conv3d16(torch.autograd.Function):
+    """Forward and data gradient: the library convolution (37 % / 28 % of the fp32 peak at config 2).  Weight gradient:
+    md_conv3d_c16_bwd_weight (the library's runs at 12 %)."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        x = x.contiguous(memory_format=torch.channels_last_3d)
+        ctx.save_for_backward(x, weight)
+        return torch.ops.aten.convolution(x, weight, None, *_CONV_ARGS)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        B, C, D, H, W = x.shape
+        gy = gy.float().contiguous(memory_format=torch.channels_last_3d)
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.ops.aten.convolution_backward(gy, x, weight, None, *_CONV_ARGS, [True, False, False])[0]
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(weight)  # keeps the weight's strides
+            s = dw.stride()
+            if s[3] != 3 * s[4] or s[2] != 9 * s[4]:
+                raise _lib.MovedepthHipError("conv3d_16: weight strides %s are not tap-regular" % (tuple(s),))
+            nbytes = _lib.load().md_conv3d_c16_bwd_weight_ws_bytes(B, D, H, W)
+            ws = _ws(nbytes, x.device)
+            _timed_call("md_conv3d_c16_bwd_weight", _p(x), _p(gy), _p(dw), s[0], s[1], s[4], _p(ws), int(nbytes), B, C,
+                        weight.shape[0], D, H, W, _stream())
+        return dx, dw
+
+
+def conv3d_16(x, weight):
+    """nn.Conv3d(16, 16, 3, stride=1, padding=1, bias=False) -- reg3d.conv0's convolution (reference
+    networks/resnet_encoder.py:231,258) with the hand-written weight gradient.  x (B,16,D,H,W) on the GPU."""
+    if not x.is_cuda or tuple(weight.shape) != (16, 16, 3, 3, 3) or x.shape[1] != 16:
+        raise _lib.MovedepthHipError("conv3d_16: needs a GPU tensor with 16 channels and a (16,16,3,3,3) weight, got %s %s %s"
+                                     % (x.device, tuple(x.shape), tuple(weight.shape)))
+    return _Conv3d16.apply(x.float(), weight.float())
+
+
 def backproject(depth, inv_K, batch_size, height, width):
     """BackprojectDepth.forward (reference layers.py:581-586), forward only -> (Bs,4,h*w)."""
     with torch.no_grad():

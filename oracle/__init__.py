@@ -310,3 +310,20 @@ def conv3d_c1_bwd(gy, x, wt):
     dx, dwt = np.empty_like(x), np.empty_like(wt)
     lib().mdo_conv3d_c1_bwd(_p(gy), _p(x), _p(wt), _i(B), _i(C), _i(D), _i(H), _i(W), _p(dx), _p(dwt))
     return dx, dwt
+
+
+def conv3d(x, wt, gy=None):
+    """reg3d.conv0's convolution (resnet_encoder.py:231,258): x [B,Ci,D,H,W], wt [Co,Ci,3,3,3] -> y [B,Co,D,H,W];
+    with gy also returns (y, dx, dwt)."""
+    x, wt = _c(x), _c(wt)
+    B, Ci, D, H, W = x.shape
+    Co = wt.shape[0]
+    assert wt.shape == (Co, Ci, 3, 3, 3)
+    y = np.empty((B, Co, D, H, W), np.float32)
+    if gy is None:
+        lib().mdo_conv3d(_p(x), _p(wt), None, _i(B), _i(Ci), _i(Co), _i(D), _i(H), _i(W), _p(y), None, None)
+        return y
+    gy = _c(gy)
+    dx, dwt = np.empty_like(x), np.empty_like(wt)
+    lib().mdo_conv3d(_p(x), _p(wt), _p(gy), _i(B), _i(Ci), _i(Co), _i(D), _i(H), _i(W), _p(y), _p(dx), _p(dwt))
+    return y, dx, dwt

@@ -965,3 +965,71 @@ void mdo_conv3d_c1_bwd(const float *gy, const float *x, const float *wt, int B, 
         }
     }
 }
+
+/* ConvBnReLU3D.conv of reg3d.conv0: nn.Conv3d(Ci, Co, 3, stride=1, padding=1, bias=False)
+ * (networks/resnet_encoder.py:231 via module.py's ConvBnReLU3D, applied :258).  NCDHW as the reference sees it:
+ * x [B,Ci,D,H,W]; wt [Co,Ci,3,3,3]; y, gy [B,Co,D,H,W].  fp64 accumulation.  Any of y / dx / dwt may be NULL. */
+void mdo_conv3d(const float *x, const float *wt, const float *gy, int B, int Ci, int Co, int D, int H, int W, float *y,
+                float *dx, float *dwt) {
+    size_t hw = (size_t)H * W, dhw = (size_t)D * hw;
+    if (y) {
+#pragma omp parallel for collapse(3)
+        for (int b = 0; b < B; ++b)
+            for (int co = 0; co < Co; ++co)
+                for (int d = 0; d < D; ++d)
+                    for (int h = 0; h < H; ++h)
+                        for (int w = 0; w < W; ++w) {
+                            double acc = 0.0;
+                            for (int ci = 0; ci < Ci; ++ci)
+                                for (int k = 0; k < 27; ++k) {
+                                    int dd = d + k / 9 - 1, hh = h + (k / 3) % 3 - 1, ww = w + k % 3 - 1;
+                                    if (dd < 0 || dd >= D || hh < 0 || hh >= H || ww < 0 || ww >= W) continue;
+                                    acc += (double)x[((size_t)b * Ci + ci) * dhw + dd * hw + (size_t)hh * W + ww] *
+                                           (double)wt[((size_t)co * Ci + ci) * 27 + k];
+                                }
+                            y[((size_t)b * Co + co) * dhw + d * hw + (size_t)h * W + w] = (float)acc;
+                        }
+    }
+    if (dx) {
+#pragma omp parallel for collapse(3)
+        for (int b = 0; b < B; ++b)
+            for (int ci = 0; ci < Ci; ++ci)
+                for (int d = 0; d < D; ++d)
+                    for (int h = 0; h < H; ++h)
+                        for (int w = 0; w < W; ++w) {
+                            double acc = 0.0;
+                            for (int co = 0; co < Co; ++co)
+                                for (int k = 0; k < 27; ++k) {
+                                    int dd = d - k / 9 + 1, hh = h - (k / 3) % 3 + 1, ww = w - k % 3 + 1;
+                                    if (dd < 0 || dd >= D || hh < 0 || hh >= H || ww < 0 || ww >= W) continue;
+                                    acc += (double)gy[((size_t)b * Co + co) * dhw + dd * hw + (size_t)hh * W + ww] *
+                                           (double)wt[((size_t)co * Ci + ci) * 27 + k];
+                                }
+                            dx[((size_t)b * Ci + ci) * dhw + d * hw + (size_t)h * W + w] = (float)acc;
+                        }
+    }
+    if (dwt) {
+#pragma omp parallel for
+        for (int o = 0; o < Co * Ci * 27; ++o) {
+            int k = o % 27, ci = (o / 27) % Ci, co = o / (27 * Ci);
+            int kd = k / 9, kh = (k / 3) % 3, kw = k % 3;
+            double acc = 0.0;
+            for (int b = 0; b < B; ++b)
+                for (int d = 0; d < D; ++d) {
+                    int dd = d + kd - 1;
+                    if (dd < 0 || dd >= D) continue;
+                    for (int h = 0; h < H; ++h) {
+                        int hh = h + kh - 1;
+                        if (hh < 0 || hh >= H) continue;
+                        for (int w = 0; w < W; ++w) {
+                            int ww = w + kw - 1;
+                            if (ww < 0 || ww >= W) continue;
+                            acc += (double)x[((size_t)b * Ci + ci) * dhw + dd * hw + (size_t)hh * W + ww] *
+                                   (double)gy[((size_t)b * Co + co) * dhw + d * hw + (size_t)h * W + w];
+                        }
+                    }
+                }
+            dwt[o] = (float)acc;
+        }
+    }
+}

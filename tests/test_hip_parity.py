@@ -523,3 +523,75 @@ def test_reg3d_prob_paths_agree(ops):
         outs.append((host(o), host(v.grad), host(net.prob.weight.grad)))
     for a, b, what in zip(outs[0], outs[1], ("logits", "d_volume", "d_prob_weight")):
         assert_close(a, b, what=what)
+
+
+# ------------------------------------------------------------------ reg3d's first layer (16 -> 16): weight gradient
+@pytest.mark.parametrize("weight_cl", [False, True])
+def test_conv0_golden(ops, weight_cl):
+    g = load_golden("conv0_c16")
+    x = _cl3d(dev(g["x"])).requires_grad_(True)
+    w = dev(g["weight"])
+    w = (_cl3d(w) if weight_cl else w).requires_grad_(True)
+    y = ops.conv3d_16(x, w)
+    assert_close(host(y), g["y"], what="conv0 y (library)")
+    (y * dev(g["grad_out"])).sum().backward()
+    assert w.grad.stride() == w.stride()
+    assert_close(host(w.grad), g["d_weight"], what="conv0 d_weight (HIP)")
+    assert_close(host(x.grad), g["d_x"], what="conv0 d_x (library)")
+
+
+@pytest.mark.parametrize("shape", [
+    (2, 19, 13, 45),   # ragged everywhere, 2 D slices
+    (1, 40, 8, 32),    # one tile, 4 slices
+    (1, 17, 20, 70),   # 3x3 tiles
+    (3, 1, 5, 3),      # a single plane smaller than the halo
+    (1, 2, 1, 1),      # one voxel column
+])
+def test_conv0_wgrad_vs_oracle(ops, oracle_lib, shape):
+    rng = np.random.default_rng(31)
+    B, D, H, W = shape
+    x = rng.standard_normal((B, 16, D, H, W)).astype(np.float32)
+    wt = (rng.standard_normal((16, 16, 3, 3, 3)) * 0.1).astype(np.float32)
+    gy = rng.standard_normal((B, 16, D, H, W)).astype(np.float32)
+    _, _, exp_dw = oracle_lib.conv3d(x, wt, gy)
+    xt, wtt = _cl3d(dev(x)), dev(wt, True)
+    y = ops.conv3d_16(xt, wtt)
+    (dw,) = torch.autograd.grad(y, wtt, _cl3d(dev(gy)))
+    assert_close(host(dw), exp_dw, what="d_weight")
+
+
+def test_conv0_wgrad_full_size_vs_library(ops):
+    """BASELINE config 2 size: against the library's weight gradient; bit-reproducible; linear in gy."""
+    torch.manual_seed(6)
+    B, D, H, W = 6, 96, 48, 160
+    x = _cl3d(torch.randn(B, 16, D, H, W, device="cuda"))
+    w = (torch.randn(16, 16, 3, 3, 3, device="cuda") * 0.05).requires_grad_(True)
+    gy = _cl3d(torch.randn(B, 16, D, H, W, device="cuda"))
+    y = ops.conv3d_16(x, w)
+    (dw,) = torch.autograd.grad(y, w, gy, retain_graph=True)
+    dw_ref = torch.ops.aten.convolution_backward(gy, x, w.detach(), None, [1] * 3, [1] * 3, [1] * 3, False, [0] * 3, 1,
+                                                 [False, True, False])[1]
+    assert_close(host(dw), host(dw_ref), what="d_weight vs library")
+    (dw2,) = torch.autograd.grad(y, w, gy, retain_graph=True)
+    assert torch.equal(dw, dw2), "weight gradient must be bit-reproducible"
+    gy2 = _cl3d(torch.randn_like(gy))
+    (dw_lin,) = torch.autograd.grad(y, w, gy + 0.5 * gy2, retain_graph=True)
+    (dw_b,) = torch.autograd.grad(y, w, gy2)
+    assert_close(host(dw_lin), host(dw + 0.5 * dw_b), what="linearity in gy")
+
+
+def test_reg3d_conv0_paths_agree(ops):
+    from movedepth_amd import networks
+    torch.manual_seed(4)
+    net = networks.reg3d(16, 16, 3).cuda().to(memory_format=torch.channels_last_3d)
+    vol = torch.randn(2, 16, 16, 24, 32, device="cuda")
+    outs = []
+    for hip in (True, False):
+        net.hip_conv0_wgrad = hip
+        net.zero_grad()
+        v = vol.clone().requires_grad_(True)
+        o = net(v)
+        o.square().mean().backward()
+        outs.append((host(o), host(v.grad), host(net.conv0.conv.weight.grad)))
+    for a, b, what in zip(outs[0], outs[1], ("logits", "d_volume", "d_conv0_weight")):
+        assert_close(a, b, what=what)

@@ -182,3 +182,12 @@ def test_prob_conv(oracle_lib, tag):
     dx, dw = oracle_lib.conv3d_c1_bwd(g["grad_out"][:, None], g["x"], g["weight"])
     assert_close(dx, g["d_x"], rtol=1e-5, what="prob d_x")
     assert_close(dw, g["d_weight"], rtol=1e-5, what="prob d_weight")
+
+
+def test_conv0(oracle_lib):
+    """reg3d's first convolution (resnet_encoder.py:231,258) through the reference's own module."""
+    g = load_golden("conv0_c16")
+    y, dx, dw = oracle_lib.conv3d(g["x"], g["weight"], g["grad_out"])
+    assert_close(y, g["y"], rtol=1e-5, what="conv0 y")
+    assert_close(dx, g["d_x"], rtol=1e-5, what="conv0 d_x")
+    assert_close(dw, g["d_weight"], rtol=1e-5, what="conv0 d_weight")

@@ -398,10 +398,25 @@ def gen_prob_conv(networks):
                                       d_weight=net.prob.weight.grad))
 
 
+def gen_conv0(networks):
+    """reg3d's first convolution through the reference's own module (conv0.conv, networks/resnet_encoder.py:231,
+    applied :258 on the permuted volume): output and both gradients.  Ragged size."""
+    g = torch.Generator().manual_seed(821)
+    torch.manual_seed(822)
+    net = networks.reg3d(16, 16, down_size=1)
+    x = torch.randn(1, 16, 6, 9, 35, generator=g).requires_grad_(True)
+    y = net.conv0.conv(x)
+    Wy = torch.randn(y.shape, generator=g)
+    (y * Wy).sum().backward()
+    save("conv0_c16", dict(x=x, weight=net.conv0.conv.weight, y=y, grad_out=Wy, d_x=x.grad,
+                           d_weight=net.conv0.conv.weight.grad))
+
+
 def main():
     torch.set_num_threads(1)
     L, Trainer, networks = load_reference(with_trainer=True)
     gen_prob_conv(networks)
+    gen_conv0(networks)
     gen_geometry(L)
     gen_schedule(L)
     gen_costvol(L)
