@@ -169,12 +169,16 @@ size_t md_conv3d_c1_bwd_weight_ws_bytes(int B, int C, int D, int H, int W);
 int md_conv3d_c1_bwd_weight(const float *x, const float *gy, float *dwt, long long dw_stride_k, long long dw_stride_c,
                             void *ws, size_t ws_bytes, int B, int C, int D, int H, int W, md_stream_t stream);
 
-/* ---- reg3d's first layer, the consumer of the grouped cost volume: weight gradient -----------------------
+/* ---- reg3d's first layer, the consumer of the grouped cost volume ------------------------------------------
  * `conv0.conv = nn.Conv3d(16, 16, 3, stride=1, padding=1, bias=False)` (networks/resnet_encoder.py:231 through
- * ConvBnReLU3D, applied :258).  x, gy: channels-last volumes [B,D,H,W,16]; dwt element (co, ci, tap k) at
- * dwt[co*dw_stride_co + ci*dw_stride_ci + k*dw_stride_k] (contiguous [16,16,3,3,3]: 432, 27, 1;
- * channels_last_3d: 432, 1, 16).  Ci == Co == 16 only (MD_EINVAL otherwise).  fp32 MFMA, fixed-order reduction.
- * The forward and the data gradient of this layer stay with the library convolution. */
+ * ConvBnReLU3D, applied :258).  x, dx, y, gy: channels-last volumes [B,D,H,W,16]; weight element (co, ci, tap k =
+ * (kd*3+kh)*3+kw) at wt[co*w_stride_co + ci*w_stride_ci + k*w_stride_k] (contiguous [16,16,3,3,3]: 432, 27, 1;
+ * channels_last_3d: 432, 1, 16), dwt likewise.  Ci == Co == 16 only (MD_EINVAL otherwise).  fp32 MFMA
+ * (v_mfma_f32_16x16x4_f32, exact fp32 products and sums); the weight gradient is reduced in a fixed order. */
+int md_conv3d_c16_fwd(const float *x, const float *wt, long long w_stride_co, long long w_stride_ci, long long w_stride_k,
+                      float *y, int B, int Ci, int Co, int D, int H, int W, md_stream_t stream);
+int md_conv3d_c16_bwd_data(const float *gy, const float *wt, long long w_stride_co, long long w_stride_ci,
+                           long long w_stride_k, float *dx, int B, int Ci, int Co, int D, int H, int W, md_stream_t stream);
 size_t md_conv3d_c16_bwd_weight_ws_bytes(int B, int D, int H, int W);
 int md_conv3d_c16_bwd_weight(const float *x, const float *gy, float *dwt, long long dw_stride_co, long long dw_stride_ci,
                              long long dw_stride_k, void *ws, size_t ws_bytes, int B, int Ci, int Co, int D, int H, int W,

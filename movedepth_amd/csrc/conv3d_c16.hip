@@ -1,11 +1,13 @@
 // 3x3x3, stride 1, pad 1, bias-free 16 -> 16 channel convolution over channels-last (NDHWC) volumes: reg3d's first
 // layer conv0 (reference networks/resnet_encoder.py:231, applied :258), the consumer of the grouped cost volume
-// (G = 16 groups = its 16 input channels).  This file: the weight gradient, which is where the library is weakest
-// (3112 us for 61 GFLOP = 19.7 TF/s at 6x16x96x48x160, profiles/r01_reg3d_layers_miopen.txt).
+// (G = 16 groups = its 16 input channels).  Library times at 6x16x96x48x160 (61 GFLOP per direction,
+// profiles/r01_reg3d_layers_miopen.txt): forward 1044 us, data gradient 1383 us, weight gradient 3112 us.
 //
+//   y[b,d,h,w,co]       = sum_{kd,kh,kw,ci} x[b,d+kd-1,h+kh-1,w+kw-1,ci] * wt[co,ci,kd,kh,kw]
+//   dx[b,d,h,w,ci]      = sum_{kd,kh,kw,co} gy[b,d-kd+1,h-kh+1,w-kw+1,co] * wt[co,ci,kd,kh,kw]
 //   dwt[co,ci,kd,kh,kw] = sum_{b,d,h,w} x[b,d+kd-1,h+kh-1,w+kw-1,ci] * gy[b,d,h,w,co]
 //
-// MFMA mapping (v_mfma_f32_16x16x4_f32, exact fp32, 157 TF/s peak = the bound of this kernel): for one tap,
+// Weight gradient, MFMA mapping (v_mfma_f32_16x16x4_f32, exact fp32, 157 TF/s peak = the bound of this kernel): for one tap,
 // D[ci][co] += sum over 4 voxels of A[ci][v] * B[v][co] with A = x at the tap-shifted voxels, B = gy.  Both operands
 // are ONE dword per lane in exactly the order the channels-last volumes have in memory (lane = voxel*16 + channel,
 // 4 consecutive voxels along w = 256 contiguous bytes), so gy goes global -> register -> MFMA and x goes
@@ -157,6 +159,92 @@ __global__ __launch_bounds__(256) void conv3d_c16_bwd_weight_finish_kernel(const
     }
 }
 
+// Forward and data gradient (one kernel): out[u][n] = sum_{tap, m} in[u + tap - 1][m] * wt(n, m, tap), where for the
+// data gradient `in` is gy, (n, m) = (ci, co) and the taps are mirrored (tap -> 26 - tap).
+// MFMA mapping: D[voxel][n] += A[voxel][m-quad] * B[m-quad][n], 16 consecutive voxels along w per group, 4 MFMAs per
+// tap (K = 4 input channels each).  Lane (voxel = l&15, kk = l>>4) gets its four A values for one tap with a single
+// ds_read_b128 (channels kk*4 .. kk*4+3 of its voxel: the 64 lanes cover 1 KB of LDS contiguously), MFMA s taking
+// channel kk*4+s; the matching B values wt(n = l&15, m = kk*4+s, tap) stay in registers for the whole kernel (108).
+__global__ __launch_bounds__(256, 2) void conv3d_c16_fwd_kernel(const float *__restrict__ in, const float *__restrict__ wt,
+                                                               long long s_n, long long s_m, long long s_k, int mirror,
+                                                               float *__restrict__ out, const C16Dims dm) {
+    __shared__ float ring[3 * PLANE_F];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, kk = lane >> 4;
+    int b, ty0, tx0, d0, d1;
+    c16_item(dm, blockIdx.x, b, ty0, tx0, d0, d1);
+    const size_t plane = (size_t)dm.H * dm.W;
+    const float4 *inb = reinterpret_cast<const float4 *>(in) + (size_t)b * dm.D * plane * 4;
+    float *outb = out + (size_t)b * dm.D * plane * CO;
+    f32x4 wr[NTAP];  // wr[tap][s] = wt(n, kk*4+s, tap)
+#pragma unroll
+    for (int k = 0; k < NTAP; ++k) {
+        const float *p = wt + n * s_n + (long long)(kk * 4) * s_m + (mirror ? 26 - k : k) * s_k;
+        wr[k] = (f32x4){p[0], p[s_m], p[2 * s_m], p[3 * s_m]};
+    }
+    int lofs[NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int idx = tid + i * 256, cell = idx >> 2, qq = idx & 3;
+        const int yy = ty0 - 1 + cell / HW_, xx = tx0 - 1 + cell % HW_;
+        lofs[i] = (idx < CELLS * 4 && yy >= 0 && yy < dm.H && xx >= 0 && xx < dm.W) ? (yy * dm.W + xx) * 4 + qq : -1;
+    }
+    float4 pre[NLD];
+    auto fetch = [&](int P) {
+        const bool inr = P >= 0 && P < dm.D;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i)
+            pre[i] = (inr && lofs[i] >= 0) ? inb[(size_t)P * plane * 4 + lofs[i]] : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    auto stash = [&](int P) {
+        float4 *slot = reinterpret_cast<float4 *>(ring + ((P + 3) % 3) * PLANE_F);
+#pragma unroll
+        for (int i = 0; i < NLD; ++i)
+            if (tid + i * 256 < CELLS * 4) slot[tid + i * 256] = pre[i];
+    };
+    fetch(d0 - 1); stash(d0 - 1);
+    fetch(d0);     stash(d0);
+    fetch(d0 + 1);
+    for (int d = d0; d < d1; ++d) {
+        stash(d + 1);
+        __syncthreads();
+        if (d + 1 < d1) fetch(d + 2);
+        const float4 *s0 = reinterpret_cast<const float4 *>(ring + ((d + 2) % 3) * PLANE_F) + kk;  // planes d-1, d, d+1
+        const float4 *s1 = reinterpret_cast<const float4 *>(ring + (d % 3) * PLANE_F) + kk;
+        const float4 *s2 = reinterpret_cast<const float4 *>(ring + ((d + 1) % 3) * PLANE_F) + kk;
+#pragma unroll 1
+        for (int g = 0; g < 4; ++g) {  // group = tile row 2*wave + g/2, columns (g%2)*16 .. +15
+            const int row = 2 * wave + (g >> 1), col0 = (g & 1) * 16;
+            const int cell = (row * HW_ + col0 + n) * 4;  // lane's voxel (n doubles as the voxel index for A), halo origin
+            f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc;  // two chains: a dependent MFMA issues 8 cycles later
+#pragma unroll
+            for (int kd = 0; kd < 3; ++kd) {
+                const float4 *sl = (kd == 0 ? s0 : kd == 1 ? s1 : s2) + cell;
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) {
+                        const float4 a = sl[(kh * HW_ + kw) * 4];
+                        const f32x4 w4 = wr[(kd * 3 + kh) * 3 + kw];
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w4[0], acc, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w4[1], acc1, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, w4[2], acc, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, w4[3], acc1, 0, 0, 0);
+                    }
+            }
+            acc += acc1;
+            // D layout: register r of lane l = out[voxel 4*(l>>4) + r][n = l&15]
+            const int yy = ty0 + row;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int xx = tx0 + col0 + 4 * kk + r;
+                if (yy < dm.H && xx < dm.W) outb[((size_t)d * plane + (size_t)yy * dm.W + xx) * CO + n] = acc[r];
+            }
+        }
+        __syncthreads();
+    }
+}
+
 int c16_dims(const char *fn, int B, int Ci, int Co, int D, int H, int W, C16Dims &dm) {
     MD_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0, "%s: bad dims B=%d D=%d H=%d W=%d", fn, B, D, H, W);
     MD_REQUIRE(Ci == CI && Co == CO, "%s: %d -> %d channels unsupported (16 -> 16 only)", fn, Ci, Co);
@@ -175,6 +263,29 @@ int c16_dims(const char *fn, int B, int Ci, int Co, int D, int H, int W, C16Dims
 }  // namespace
 
 extern "C" {
+
+static int c16_launch_fwd(const char *fn, const float *in, const float *wt, long long s_n, long long s_m, long long s_k, int mirror,
+                          float *out, int B, int Ci, int Co, int D, int H, int W, md_stream_t stream) {
+    MD_REQUIRE(in && wt && out, "%s: null tensor argument", fn);
+    MD_REQUIRE(((uintptr_t)in % 16) == 0, "%s: the input volume must be 16-byte aligned", fn);
+    C16Dims dm;
+    if (int rc = c16_dims(fn, B, Ci, Co, D, H, W, dm)) return rc;
+    hipLaunchKernelGGL(conv3d_c16_fwd_kernel, dim3(B * dm.tiles * dm.dslices), dim3(256), 0, (hipStream_t)stream, in, wt, s_n,
+                       s_m, s_k, mirror, out, dm);
+    MD_CHECK_LAUNCH(fn);
+    return MD_OK;
+}
+
+int md_conv3d_c16_fwd(const float *x, const float *wt, long long w_stride_co, long long w_stride_ci, long long w_stride_k,
+                      float *y, int B, int Ci, int Co, int D, int H, int W, md_stream_t stream) {
+    return c16_launch_fwd("md_conv3d_c16_fwd", x, wt, w_stride_co, w_stride_ci, w_stride_k, 0, y, B, Ci, Co, D, H, W, stream);
+}
+
+int md_conv3d_c16_bwd_data(const float *gy, const float *wt, long long w_stride_co, long long w_stride_ci,
+                           long long w_stride_k, float *dx, int B, int Ci, int Co, int D, int H, int W, md_stream_t stream) {
+    return c16_launch_fwd("md_conv3d_c16_bwd_data", gy, wt, w_stride_ci, w_stride_co, w_stride_k, 1, dx, B, Ci, Co, D, H, W,
+                          stream);
+}
 
 size_t md_conv3d_c16_bwd_weight_ws_bytes(int B, int D, int H, int W) {
     C16Dims dm;

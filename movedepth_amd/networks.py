@@ -341,7 +341,8 @@ class reg3d(nn.Module):
     # compilation.  torch reads the benchmark flag when a conv (or its backward) executes, so it is switched on
     # around the forward and, through tensor hooks, around this module's part of the backward pass.
     find_convs = True
-    hip_conv0_wgrad = True
+    hip_conv0_wgrad = True        # False: the whole first convolution on the library
+    lib_conv0_fwd_dgrad = False   # True: only its weight gradient hand-written (A/B)
     hip_prob = True   # False: keep `prob` on the library convolution too (used by the A/B in tools/ and tests)
 
     def forward(self, inputs):
@@ -368,8 +369,8 @@ class reg3d(nn.Module):
             not self.conv0.conv.weight.is_contiguous()
         x = x.contiguous(memory_format=torch.channels_last_3d) if cl else x.contiguous()
         if cl and x.is_cuda and self.hip_conv0_wgrad and tuple(self.conv0.conv.weight.shape) == (16, 16, 3, 3, 3):
-            # first layer: library forward / data gradient, hand-written MFMA weight gradient (library: 3.1 ms)
-            c0 = F.relu(self.conv0.bn(ops.conv3d_16(x, self.conv0.conv.weight)), inplace=True)
+            # first layer on the MFMA kernels (library: 1.0 / 1.4 / 3.1 ms fwd / data gradient / weight gradient)
+            c0 = F.relu(self.conv0.bn(ops.conv3d_16(x, self.conv0.conv.weight, self.lib_conv0_fwd_dgrad)), inplace=True)
         else:
             c0 = self.conv0(x)
         c2 = self.conv2(self.conv1(c0))

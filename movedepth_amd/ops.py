@@ -507,15 +507,29 @@ def conv3d_c1(x, weight):
 _CONV_ARGS = ([1, 1, 1], [1, 1, 1], [1, 1, 1], False, [0, 0, 0], 1)  # stride, padding, dilation, transposed, out pad, groups
 
 
+def _c16_weight_strides(w):
+    s = w.stride()
+    if s[3] != 3 * s[4] or s[2] != 9 * s[4]:
+        raise _lib.MovedepthHipError("conv3d_16: weight strides %s are not tap-regular" % (tuple(s),))
+    return s[0], s[1], s[4]
+
+
 class _Conv3d16(torch.autograd.Function):
-    """Forward and data gradient: the library convolution (37 % / 28 % of the fp32 peak at config 2).  Weight gradient:
-    md_conv3d_c16_bwd_weight (the library's runs at 12 %)."""
+    """reg3d.conv0's convolution on the MFMA kernels of csrc/conv3d_c16.hip.  `lib_fwd_dgrad` keeps the forward and the
+    data gradient on the library convolution (A/B switch; the weight gradient is always the hand-written one)."""
 
     @staticmethod
-    def forward(ctx, x, weight):
+    def forward(ctx, x, weight, lib_fwd_dgrad):
         x = x.contiguous(memory_format=torch.channels_last_3d)
         ctx.save_for_backward(x, weight)
-        return torch.ops.aten.convolution(x, weight, None, *_CONV_ARGS)
+        ctx.lib = bool(lib_fwd_dgrad)
+        if ctx.lib:
+            return torch.ops.aten.convolution(x, weight, None, *_CONV_ARGS)
+        B, C, D, H, W = x.shape
+        y = torch.empty_like(x, memory_format=torch.channels_last_3d)
+        _timed_call("md_conv3d_c16_fwd", _p(x), _p(weight), *_c16_weight_strides(weight), _p(y), B, C, weight.shape[0], D, H, W,
+                    _stream())
+        return y
 
     @staticmethod
     def backward(ctx, gy):
@@ -524,26 +538,29 @@ class _Conv3d16(torch.autograd.Function):
         gy = gy.float().contiguous(memory_format=torch.channels_last_3d)
         dx = dw = None
         if ctx.needs_input_grad[0]:
-            dx = torch.ops.aten.convolution_backward(gy, x, weight, None, *_CONV_ARGS, [True, False, False])[0]
+            if ctx.lib:
+                dx = torch.ops.aten.convolution_backward(gy, x, weight, None, *_CONV_ARGS, [True, False, False])[0]
+            else:
+                dx = torch.empty_like(x, memory_format=torch.channels_last_3d)
+                _timed_call("md_conv3d_c16_bwd_data", _p(gy), _p(weight), *_c16_weight_strides(weight), _p(dx), B, C,
+                            weight.shape[0], D, H, W, _stream())
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(weight)  # keeps the weight's strides
-            s = dw.stride()
-            if s[3] != 3 * s[4] or s[2] != 9 * s[4]:
-                raise _lib.MovedepthHipError("conv3d_16: weight strides %s are not tap-regular" % (tuple(s),))
             nbytes = _lib.load().md_conv3d_c16_bwd_weight_ws_bytes(B, D, H, W)
             ws = _ws(nbytes, x.device)
-            _timed_call("md_conv3d_c16_bwd_weight", _p(x), _p(gy), _p(dw), s[0], s[1], s[4], _p(ws), int(nbytes), B, C,
+            _timed_call("md_conv3d_c16_bwd_weight", _p(x), _p(gy), _p(dw), *_c16_weight_strides(dw), _p(ws), int(nbytes), B, C,
                         weight.shape[0], D, H, W, _stream())
-        return dx, dw
+        return dx, dw, None
 
 
-def conv3d_16(x, weight):
+def conv3d_16(x, weight, lib_fwd_dgrad=False):
     """nn.Conv3d(16, 16, 3, stride=1, padding=1, bias=False) -- reg3d.conv0's convolution (reference
-    networks/resnet_encoder.py:231,258) with the hand-written weight gradient.  x (B,16,D,H,W) on the GPU."""
+    networks/resnet_encoder.py:231,258).  x (B,16,D,H,W) on the GPU, read as channels_last_3d; weight (16,16,3,3,3) in
+    either memory format; returns a channels_last_3d (B,16,D,H,W) tensor."""
     if not x.is_cuda or tuple(weight.shape) != (16, 16, 3, 3, 3) or x.shape[1] != 16:
         raise _lib.MovedepthHipError("conv3d_16: needs a GPU tensor with 16 channels and a (16,16,3,3,3) weight, got %s %s %s"
                                      % (x.device, tuple(x.shape), tuple(weight.shape)))
-    return _Conv3d16.apply(x.float(), weight.float())
+    return _Conv3d16.apply(x.float(), weight.float(), lib_fwd_dgrad)
 
 
 def backproject(depth, inv_K, batch_size, height, width):

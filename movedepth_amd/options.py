@@ -82,8 +82,9 @@ class MonodepthOptions:
                        help="run the 3-D regulariser in channels_last_3d and write the cost volume as (B,D,h,w,G)")
         p.add_argument("--hip_prob_conv", type=int, default=1,
                        help="the 3-D regulariser's last (C->1) convolution on the hand-written kernels (0: library)")
-        p.add_argument("--hip_conv0_wgrad", type=int, default=1,
-                       help="the 3-D regulariser's first convolution: hand-written weight gradient (0: library)")
+        p.add_argument("--hip_conv0", default="all", choices=["all", "wgrad", "none"],
+                       help="the 3-D regulariser's first convolution on the MFMA kernels: all three directions, the "
+                            "weight gradient only, or none (library)")
         p.add_argument("--sync_bn", type=int, default=1, help="with --ddp: convert BatchNorm to SyncBatchNorm (reference)")
         p.add_argument("--grad_bucket_mb", type=float, default=32.0, help="with --ddp: all-reduce bucket size")
         self.parser = p

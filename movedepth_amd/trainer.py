@@ -82,7 +82,8 @@ class Trainer:
         # the HIP kernel) with MIOpen's solver search enabled for its convs only (see networks.reg3d)
         self.models["reg3d"].find_convs = bool(opt.miopen_find)
         self.models["reg3d"].hip_prob = bool(opt.hip_prob_conv)
-        self.models["reg3d"].hip_conv0_wgrad = bool(opt.hip_conv0_wgrad)
+        self.models["reg3d"].hip_conv0_wgrad = opt.hip_conv0 != "none"
+        self.models["reg3d"].lib_conv0_fwd_dgrad = opt.hip_conv0 == "wgrad"
         self.vol_layout = "bgd"
         if opt.reg3d_channels_last and opt.num_depth_bins >= 8:
             self.models["reg3d"] = self.models["reg3d"].to(memory_format=torch.channels_last_3d)

@@ -526,18 +526,19 @@ def test_reg3d_prob_paths_agree(ops):
 
 
 # ------------------------------------------------------------------ reg3d's first layer (16 -> 16): weight gradient
+@pytest.mark.parametrize("lib_fwd_dgrad", [False, True])
 @pytest.mark.parametrize("weight_cl", [False, True])
-def test_conv0_golden(ops, weight_cl):
+def test_conv0_golden(ops, weight_cl, lib_fwd_dgrad):
     g = load_golden("conv0_c16")
     x = _cl3d(dev(g["x"])).requires_grad_(True)
     w = dev(g["weight"])
     w = (_cl3d(w) if weight_cl else w).requires_grad_(True)
-    y = ops.conv3d_16(x, w)
-    assert_close(host(y), g["y"], what="conv0 y (library)")
+    y = ops.conv3d_16(x, w, lib_fwd_dgrad)
+    assert_close(host(y), g["y"], what="conv0 y")
     (y * dev(g["grad_out"])).sum().backward()
-    assert w.grad.stride() == w.stride()
-    assert_close(host(w.grad), g["d_weight"], what="conv0 d_weight (HIP)")
-    assert_close(host(x.grad), g["d_x"], what="conv0 d_x (library)")
+    assert w.grad.stride() == w.stride() and x.grad.is_contiguous(memory_format=torch.channels_last_3d)
+    assert_close(host(w.grad), g["d_weight"], what="conv0 d_weight")
+    assert_close(host(x.grad), g["d_x"], what="conv0 d_x")
 
 
 @pytest.mark.parametrize("shape", [
@@ -547,31 +548,39 @@ def test_conv0_golden(ops, weight_cl):
     (3, 1, 5, 3),      # a single plane smaller than the halo
     (1, 2, 1, 1),      # one voxel column
 ])
-def test_conv0_wgrad_vs_oracle(ops, oracle_lib, shape):
+def test_conv0_vs_oracle(ops, oracle_lib, shape):
     rng = np.random.default_rng(31)
     B, D, H, W = shape
     x = rng.standard_normal((B, 16, D, H, W)).astype(np.float32)
     wt = (rng.standard_normal((16, 16, 3, 3, 3)) * 0.1).astype(np.float32)
     gy = rng.standard_normal((B, 16, D, H, W)).astype(np.float32)
-    _, _, exp_dw = oracle_lib.conv3d(x, wt, gy)
-    xt, wtt = _cl3d(dev(x)), dev(wt, True)
+    exp_y, exp_dx, exp_dw = oracle_lib.conv3d(x, wt, gy)
+    xt, wtt = _cl3d(dev(x)).requires_grad_(True), dev(wt, True)
     y = ops.conv3d_16(xt, wtt)
-    (dw,) = torch.autograd.grad(y, wtt, _cl3d(dev(gy)))
+    assert_close(host(y), exp_y, what="y")
+    dx, dw = torch.autograd.grad(y, (xt, wtt), _cl3d(dev(gy)))
+    assert_close(host(dx), exp_dx, what="d_x")
     assert_close(host(dw), exp_dw, what="d_weight")
 
 
-def test_conv0_wgrad_full_size_vs_library(ops):
-    """BASELINE config 2 size: against the library's weight gradient; bit-reproducible; linear in gy."""
+def test_conv0_full_size_vs_library(ops):
+    """BASELINE config 2 size: all three directions against the library; weight gradient bit-reproducible and linear
+    in gy; forward / data gradient adjoint to each other (<y, gy> == <x, dx>, a size-independent property)."""
     torch.manual_seed(6)
     B, D, H, W = 6, 96, 48, 160
-    x = _cl3d(torch.randn(B, 16, D, H, W, device="cuda"))
+    x = _cl3d(torch.randn(B, 16, D, H, W, device="cuda")).requires_grad_(True)
     w = (torch.randn(16, 16, 3, 3, 3, device="cuda") * 0.05).requires_grad_(True)
     gy = _cl3d(torch.randn(B, 16, D, H, W, device="cuda"))
     y = ops.conv3d_16(x, w)
-    (dw,) = torch.autograd.grad(y, w, gy, retain_graph=True)
-    dw_ref = torch.ops.aten.convolution_backward(gy, x, w.detach(), None, [1] * 3, [1] * 3, [1] * 3, False, [0] * 3, 1,
-                                                 [False, True, False])[1]
+    dx, dw = torch.autograd.grad(y, (x, w), gy, retain_graph=True)
+    y_ref = torch.nn.functional.conv3d(x.detach(), w.detach(), padding=1)
+    dx_ref, dw_ref, _ = torch.ops.aten.convolution_backward(gy, x.detach(), w.detach(), None, [1] * 3, [1] * 3, [1] * 3, False,
+                                                            [0] * 3, 1, [True, True, False])
+    assert_close(host(y), host(y_ref), what="y vs library")
+    assert_close(host(dx), host(dx_ref), what="d_x vs library")
     assert_close(host(dw), host(dw_ref), what="d_weight vs library")
+    lhs, rhs = (y.detach().double() * gy.double()).sum().item(), (x.detach().double() * dx.double()).sum().item()
+    assert abs(lhs - rhs) <= 1e-5 * max(abs(lhs), abs(rhs), 1.0), "forward and data gradient are not adjoint: %r %r" % (lhs, rhs)
     (dw2,) = torch.autograd.grad(y, w, gy, retain_graph=True)
     assert torch.equal(dw, dw2), "weight gradient must be bit-reproducible"
     gy2 = _cl3d(torch.randn_like(gy))
@@ -586,12 +595,13 @@ def test_reg3d_conv0_paths_agree(ops):
     net = networks.reg3d(16, 16, 3).cuda().to(memory_format=torch.channels_last_3d)
     vol = torch.randn(2, 16, 16, 24, 32, device="cuda")
     outs = []
-    for hip in (True, False):
-        net.hip_conv0_wgrad = hip
+    for hip, lib_fd in ((True, False), (True, True), (False, False)):
+        net.hip_conv0_wgrad, net.lib_conv0_fwd_dgrad = hip, lib_fd
         net.zero_grad()
         v = vol.clone().requires_grad_(True)
         o = net(v)
         o.square().mean().backward()
         outs.append((host(o), host(v.grad), host(net.conv0.conv.weight.grad)))
-    for a, b, what in zip(outs[0], outs[1], ("logits", "d_volume", "d_conv0_weight")):
-        assert_close(a, b, what=what)
+    for other in outs[:2]:
+        for a, b, what in zip(other, outs[2], ("logits", "d_volume", "d_conv0_weight")):
+            assert_close(a, b, what=what)

@@ -26,12 +26,16 @@ def ev(fn, n=20, warm=3):
     return s.elapsed_time(e) / n * 1e3
 
 
+# one graph per direction: needs_input_grad follows requires_grad of the forward's inputs, so a graph in which both x
+# and w require grad runs BOTH backward kernels whatever `inputs=` autograd.grad is given (the first version of this
+# script did that and reported the sum of the two as each one's time)
 xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
-yh = ops.conv3d_c1(xr, wr)
+yh_dx = ops.conv3d_c1(xr, w)
+yh_dw = ops.conv3d_c1(x, wr)
 mask = lambda m: torch.ops.aten.convolution_backward(gy, x, w, None, [1] * 3, [1] * 3, [1] * 3, False, [0] * 3, 1, m)
 rows = [("fwd", lambda: ops.conv3d_c1(x, w), lambda: torch.nn.functional.conv3d(x, w, padding=1), xb + yb),
-        ("bwd-data", lambda: torch.autograd.grad(yh, xr, gy, retain_graph=True), lambda: mask([True, False, False]), xb + yb),
-        ("bwd-weight", lambda: torch.autograd.grad(yh, wr, gy, retain_graph=True), lambda: mask([False, True, False]), xb + yb)]
+        ("bwd-data", lambda: torch.autograd.grad(yh_dx, xr, gy, retain_graph=True), lambda: mask([True, False, False]), xb + yb),
+        ("bwd-weight", lambda: torch.autograd.grad(yh_dw, wr, gy, retain_graph=True), lambda: mask([False, True, False]), xb + yb)]
 skip_lib = os.environ.get("NO_LIB") == "1"
 print("conv3d_c1 B=%d C=%d %dx%dx%d  lib=%s" % (B, C, D, H, W, os.environ.get("MOVEDEPTH_HIP_LIB", "default")))
 for name, mine, lib, nbytes in rows:

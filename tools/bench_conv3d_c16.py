@@ -1,4 +1,4 @@
-"""GPU: reg3d.conv0's weight gradient, hand-written MFMA kernel against the library, BASELINE config-2 volume."""
+"""GPU: reg3d.conv0 (16->16, 3x3x3) on the hand-written MFMA kernels against the library, BASELINE config-2 volume."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -7,11 +7,11 @@ from movedepth_amd import ops
 torch.backends.cudnn.benchmark = True
 B, D, H, W = 6, 96, 48, 160
 cl = lambda t: t.contiguous(memory_format=torch.channels_last_3d)
-x = cl(torch.randn(B, 16, D, H, W, device="cuda"))
+x = cl(torch.randn(B, 16, D, H, W, device="cuda")).requires_grad_(True)
 w = cl(torch.randn(16, 16, 3, 3, 3, device="cuda") * 0.05).requires_grad_(True)
 gy = cl(torch.randn(B, 16, D, H, W, device="cuda"))
-y = ops.conv3d_16(x, w)
 gflop = 2 * 27 * 16 * 16 * B * D * H * W / 1e9
+ARGS = ([1] * 3, [1] * 3, [1] * 3, False, [0] * 3, 1)
 
 
 def ev(fn, n=10, warm=3):
@@ -26,8 +26,19 @@ def ev(fn, n=10, warm=3):
     return s.elapsed_time(e) / n * 1e3
 
 
-t = ev(lambda: torch.autograd.grad(y, w, gy, retain_graph=True))
-tl = ev(lambda: torch.ops.aten.convolution_backward(gy, x, w.detach(), None, [1] * 3, [1] * 3, [1] * 3, False, [0] * 3, 1,
-                                                    [False, True, False]), n=5, warm=2)
-print("conv0 weight gradient 16->16 %dx%dx%dx%d: HIP %.1f us = %.1f TF/s (%.1f%% of 157.3 fp32 peak)   library %.1f us = %.1f TF/s"
-      % (B, D, H, W, t, gflop / t * 1e3, gflop / t * 1e3 / 157.3 * 100, tl, gflop / tl * 1e3))  # GFLOP / us * 1e3 = TF/s
+xd, wd = x.detach(), w.detach()
+# one graph per direction, so that the backward of each row runs exactly one kernel (needs_input_grad follows
+# requires_grad of the forward's inputs, not the `inputs=` of autograd.grad)
+y_dx = ops.conv3d_16(x, wd)
+y_dw = ops.conv3d_16(xd, w)
+rows = [("fwd", lambda: ops.conv3d_16(xd, wd), lambda: torch.ops.aten.convolution(xd, wd, None, *ARGS)),
+        ("bwd-data", lambda: torch.autograd.grad(y_dx, x, gy, retain_graph=True),
+         lambda: torch.ops.aten.convolution_backward(gy, xd, wd, None, *ARGS, [True, False, False])),
+        ("bwd-weight", lambda: torch.autograd.grad(y_dw, w, gy, retain_graph=True),
+         lambda: torch.ops.aten.convolution_backward(gy, xd, wd, None, *ARGS, [False, True, False]))]
+print("conv0 16->16 %dx%dx%dx%d, %.1f GFLOP per direction, fp32 MFMA peak 157.3 TF/s" % (B, D, H, W, gflop))
+for name, mine, lib in rows:
+    t, tl = ev(mine), ev(lib, n=5, warm=2)
+    # GFLOP / us * 1e3 = TF/s
+    print("  %-10s HIP %7.1f us = %5.1f TF/s (%4.1f%% of peak)   library %7.1f us = %5.1f TF/s"
+          % (name, t, gflop / t * 1e3, gflop / t * 1e3 / 157.3 * 100, tl, gflop / tl * 1e3), flush=True)
