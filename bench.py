@@ -147,7 +147,9 @@ def main():
 
     for _ in range(a.warmup):
         trainer.train_step(dict(inputs))
-    ops.enable_kernel_timing(["md_costvol_fwd", "md_costvol_bwd"])
+    CONV_KERNELS = ["md_conv3d_c16_fwd", "md_conv3d_c16_bwd_data", "md_conv3d_c16_bwd_weight", "md_conv3d_c1_fwd",
+                    "md_conv3d_c1_bwd_data", "md_conv3d_c1_bwd_weight"]
+    ops.enable_kernel_timing(["md_costvol_fwd", "md_costvol_bwd"] + CONV_KERNELS)
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -185,6 +187,24 @@ def main():
                          "avg_launch_us": kt.get("avg_us"), "launches_timed": kt.get("launches"),
                          "bwd_avg_launch_us": times.get("md_costvol_bwd", {}).get("avg_us")},
         }
+        # the 3-D regulariser's first / last convolutions (hand-off either side of it), same live HIP-event timing:
+        # 16->16 is MFMA-bound (2*27*16*16 flop per voxel against the 157.3 TF/s fp32 MFMA peak), 16->1 is HBM-bound
+        # (the 16-channel volume read or written once plus the 1-channel one)
+        vox = opt.batch_size * opt.num_depth_bins * h * w
+        conv = {}
+        for name in CONV_KERNELS:
+            kc = times.get(name)
+            if not kc:
+                continue
+            e = {"avg_us": kc["avg_us"], "launches_timed": kc["launches"]}
+            if "c16" in name:
+                e["bound"], e["achieved"], e["peak"], e["unit"] = "mfma", 2 * 27 * 16 * 16 * vox / kc["avg_us"] * 1e-6, 157.3, "TFLOP/s"
+            else:
+                e["bound"], e["achieved"], e["peak"], e["unit"] = "hbm", 4 * vox * (opt.reg3d_c + 1) / kc["avg_us"] * 1e-3, HBM_PEAK_GBS, "GB/s"
+            e["frac"] = e["achieved"] / e["peak"]
+            conv[name] = e
+        if conv:
+            out["reg3d_handoff_kernels"] = conv
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(opt)
         print(json.dumps(out))
