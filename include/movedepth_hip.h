@@ -174,15 +174,19 @@ int md_conv3d_c1_bwd_weight(const float *x, const float *gy, float *dwt, long lo
  * ConvBnReLU3D, applied :258).  x, dx, y, gy: channels-last volumes [B,D,H,W,16]; weight element (co, ci, tap k =
  * (kd*3+kh)*3+kw) at wt[co*w_stride_co + ci*w_stride_ci + k*w_stride_k] (contiguous [16,16,3,3,3]: 432, 27, 1;
  * channels_last_3d: 432, 1, 16), dwt likewise.  Ci == Co == 16 only (MD_EINVAL otherwise).  fp32 MFMA
- * (v_mfma_f32_16x16x4_f32, exact fp32 products and sums); the weight gradient is reduced in a fixed order. */
-int md_conv3d_c16_fwd(const float *x, const float *wt, long long w_stride_co, long long w_stride_ci, long long w_stride_k,
-                      float *y, int B, int Ci, int Co, int D, int H, int W, md_stream_t stream);
+ * (v_mfma_f32_16x16x4_f32, exact fp32 products and sums); the weight gradient is reduced in a fixed order.
+ * x_planar / dx_planar != 0: that volume is planar [B,16,D,H,W] instead -- the cost volume's `bgd` layout as
+ * md_costvol_fwd writes it and md_costvol_bwd reads its gradient (sb = 16*D*h*w, sg = D*h*w, sd = h*w, sp = 1), so
+ * the plane-sweep kernels run in their fastest layout and no layout copy sits between them and this layer. */
+int md_conv3d_c16_fwd(const float *x, int x_planar, const float *wt, long long w_stride_co, long long w_stride_ci,
+                      long long w_stride_k, float *y, int B, int Ci, int Co, int D, int H, int W, md_stream_t stream);
 int md_conv3d_c16_bwd_data(const float *gy, const float *wt, long long w_stride_co, long long w_stride_ci,
-                           long long w_stride_k, float *dx, int B, int Ci, int Co, int D, int H, int W, md_stream_t stream);
+                           long long w_stride_k, float *dx, int dx_planar, int B, int Ci, int Co, int D, int H, int W,
+                           md_stream_t stream);
 size_t md_conv3d_c16_bwd_weight_ws_bytes(int B, int D, int H, int W);
-int md_conv3d_c16_bwd_weight(const float *x, const float *gy, float *dwt, long long dw_stride_co, long long dw_stride_ci,
-                             long long dw_stride_k, void *ws, size_t ws_bytes, int B, int Ci, int Co, int D, int H, int W,
-                             md_stream_t stream);
+int md_conv3d_c16_bwd_weight(const float *x, int x_planar, const float *gy, float *dwt, long long dw_stride_co,
+                             long long dw_stride_ci, long long dw_stride_k, void *ws, size_t ws_bytes, int B, int Ci, int Co,
+                             int D, int H, int W, md_stream_t stream);
 
 /* ---- standalone geometry, for call compatibility (the hot kernels fuse these; forward only) -------
  * BackprojectDepth.forward (layers.py:581-586): depth [Bs,h*w], invK [nk,4,4] (nk = 1 or Bs) -> cam_points [Bs,4,h*w].

@@ -42,6 +42,68 @@ __device__ __forceinline__ void c16_item(const C16Dims &dm, int item, int &b, in
     d1 = min(d0 + dm.planes, dm.D);
 }
 
+// Stages one tile plane (+1 halo, zeros outside the volume) of a 16-channel volume into an LDS slot through registers
+// (fetch early, stash after the previous plane's consumers are done).
+//   channels-last volume [B,D,H,W,16]: LDS slot = [cell][16], a straight copy in memory order (float4 pieces);
+//   planar volume [B,16,D,H,W] (the cost volume's `bgd` layout): LDS slot = [16][CELLS], also a straight copy (dwords);
+//     channel stride 340 floats = 20 mod 64 banks, so the MFMA operand reads (16 channels x 4 voxels, or 4 channels x
+//     16 voxels per wave) touch 64 distinct banks.
+template <bool PLANAR>
+struct Stager {
+    static constexpr int N = PLANAR ? (CELLS * CI + 255) / 256 : NLD;
+    int ofs[N];
+    float4 pre4[PLANAR ? 1 : N];
+    float pre1[PLANAR ? N : 1];
+    size_t pstride;  // elements between consecutive planes (in units of the piece type)
+
+    __device__ __forceinline__ void init(const C16Dims &dm, int ty0, int tx0) {
+        const int tid = threadIdx.x;
+        const size_t plane = (size_t)dm.H * dm.W;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const int idx = tid + i * 256;
+            if (PLANAR) {
+                const int c = idx / CELLS, cell = idx % CELLS;
+                const int yy = ty0 - 1 + cell / HW_, xx = tx0 - 1 + cell % HW_;
+                ofs[i] = (idx < CELLS * CI && yy >= 0 && yy < dm.H && xx >= 0 && xx < dm.W)
+                             ? (int)(c * dm.D * plane) + yy * dm.W + xx : -1;
+            } else {
+                const int cell = idx >> 2, qq = idx & 3;
+                const int yy = ty0 - 1 + cell / HW_, xx = tx0 - 1 + cell % HW_;
+                ofs[i] = (idx < CELLS * 4 && yy >= 0 && yy < dm.H && xx >= 0 && xx < dm.W) ? (yy * dm.W + xx) * 4 + qq : -1;
+            }
+        }
+        pstride = PLANAR ? plane : plane * 4;
+    }
+    // `base`: the sample's volume (float* for planar, float4* view for channels-last)
+    __device__ __forceinline__ void fetch(const float *__restrict__ base, const C16Dims &dm, int P) {
+        const bool in = P >= 0 && P < dm.D;
+        if (PLANAR) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) pre1[i] = (in && ofs[i] >= 0) ? base[(size_t)P * pstride + ofs[i]] : 0.f;
+        } else {
+            const float4 *b4 = reinterpret_cast<const float4 *>(base);
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+                pre4[i] = (in && ofs[i] >= 0) ? b4[(size_t)P * pstride + ofs[i]] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    __device__ __forceinline__ void stash(float *slot) const {
+        const int tid = threadIdx.x;
+        if (PLANAR) {
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+                if (tid + i * 256 < CELLS * CI) slot[tid + i * 256] = pre1[i];
+        } else {
+            float4 *s4 = reinterpret_cast<float4 *>(slot);
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+                if (tid + i * 256 < CELLS * 4) s4[tid + i * 256] = pre4[i];
+        }
+    }
+};
+
+template <bool XPLANAR>
 __global__ __launch_bounds__(256, 2) void conv3d_c16_bwd_weight_kernel(const float *__restrict__ x, const float *__restrict__ gy,
                                                                       float *__restrict__ partial, const C16Dims dm) {
     __shared__ float ring[3 * PLANE_F];  // plane P in slot (P + 3) % 3; reused for the wave reduction at the end
@@ -50,30 +112,12 @@ __global__ __launch_bounds__(256, 2) void conv3d_c16_bwd_weight_kernel(const flo
     int b, ty0, tx0, d0, d1;
     c16_item(dm, blockIdx.x, b, ty0, tx0, d0, d1);
     const size_t plane = (size_t)dm.H * dm.W;
-    const float4 *xb = reinterpret_cast<const float4 *>(x) + (size_t)b * dm.D * plane * 4;
+    const float *xb = x + (size_t)b * dm.D * plane * CI;
     const float *gyb = gy + (size_t)b * dm.D * plane * CO;
-
-    // x staging roles: piece idx = cell * 4 + quad, memory order along a tile row
-    int lofs[NLD];
-#pragma unroll
-    for (int i = 0; i < NLD; ++i) {
-        const int idx = tid + i * 256, cell = idx >> 2, qq = idx & 3;
-        const int yy = ty0 - 1 + cell / HW_, xx = tx0 - 1 + cell % HW_;
-        lofs[i] = (idx < CELLS * 4 && yy >= 0 && yy < dm.H && xx >= 0 && xx < dm.W) ? (yy * dm.W + xx) * 4 + qq : -1;
-    }
-    float4 pre[NLD];
-    auto fetch = [&](int P) {
-        const bool in = P >= 0 && P < dm.D;
-#pragma unroll
-        for (int i = 0; i < NLD; ++i)
-            pre[i] = (in && lofs[i] >= 0) ? xb[(size_t)P * plane * 4 + lofs[i]] : make_float4(0.f, 0.f, 0.f, 0.f);
-    };
-    auto stash = [&](int P) {
-        float4 *slot = reinterpret_cast<float4 *>(ring + ((P + 3) % 3) * PLANE_F);
-#pragma unroll
-        for (int i = 0; i < NLD; ++i)
-            if (tid + i * 256 < CELLS * 4) slot[tid + i * 256] = pre[i];
-    };
+    Stager<XPLANAR> st;
+    st.init(dm, ty0, tx0);
+    auto fetch = [&](int P) { st.fetch(xb, dm, P); };
+    auto stash = [&](int P) { st.stash(ring + ((P + 3) % 3) * PLANE_F); };
     // gy roles: group g of this wave = tile row 2*wave + g/8, columns (g%8)*4 .. +3; lane holds (voxel v, channel ch)
     auto gy_load = [&](int d, int g) -> float {
         const int yy = ty0 + 2 * wave + (g >> 3), xx = tx0 + (g & 7) * 4 + v;
@@ -92,13 +136,16 @@ __global__ __launch_bounds__(256, 2) void conv3d_c16_bwd_weight_kernel(const flo
         stash(d + 1);
         __syncthreads();
         if (d + 1 < d1) fetch(d + 2);
-        const float *s0 = ring + ((d + 2) % 3) * PLANE_F + ch;  // planes d-1, d, d+1
-        const float *s1 = ring + (d % 3) * PLANE_F + ch;
-        const float *s2 = ring + ((d + 1) % 3) * PLANE_F + ch;
+        // element (cell, channel) of a slot sits at cell*16 + ch (channels-last) or ch*CELLS + cell (planar)
+        constexpr int CS = XPLANAR ? 1 : CI;
+        const int chofs = XPLANAR ? ch * CELLS : ch;
+        const float *s0 = ring + ((d + 2) % 3) * PLANE_F + chofs;  // planes d-1, d, d+1
+        const float *s1 = ring + (d % 3) * PLANE_F + chofs;
+        const float *s2 = ring + ((d + 1) % 3) * PLANE_F + chofs;
 #pragma unroll 1
         for (int g = 0; g < 16; ++g) {
             const float gnext = gy_load(d, (g + 1) & 15);  // one group ahead (the wrap-around load is discarded)
-            const int cell = ((2 * wave + (g >> 3)) * HW_ + (g & 7) * 4 + v) * CI;  // this lane's voxel, halo origin
+            const int cell = ((2 * wave + (g >> 3)) * HW_ + (g & 7) * 4 + v) * CS;  // this lane's voxel, halo origin
 #pragma unroll
             for (int kd = 0; kd < 3; ++kd) {
                 const float *sl = (kd == 0 ? s0 : kd == 1 ? s1 : s2) + cell;
@@ -106,7 +153,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_c16_bwd_weight_kernel(const flo
                 for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
                     for (int kw = 0; kw < 3; ++kw) {
-                        const float a = sl[(kh * HW_ + kw) * CI];
+                        const float a = sl[(kh * HW_ + kw) * CS];
                         const int k = (kd * 3 + kh) * 3 + kw;
                         acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, gcur, acc[k], 0, 0, 0);
                     }
@@ -165,6 +212,7 @@ __global__ __launch_bounds__(256) void conv3d_c16_bwd_weight_finish_kernel(const
 // tap (K = 4 input channels each).  Lane (voxel = l&15, kk = l>>4) gets its four A values for one tap with a single
 // ds_read_b128 (channels kk*4 .. kk*4+3 of its voxel: the 64 lanes cover 1 KB of LDS contiguously), MFMA s taking
 // channel kk*4+s; the matching B values wt(n = l&15, m = kk*4+s, tap) stay in registers for the whole kernel (108).
+template <bool IN_PLANAR, bool OUT_PLANAR>
 __global__ __launch_bounds__(256, 2) void conv3d_c16_fwd_kernel(const float *__restrict__ in, const float *__restrict__ wt,
                                                                long long s_n, long long s_m, long long s_k, int mirror,
                                                                float *__restrict__ out, const C16Dims dm) {
@@ -174,7 +222,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_c16_fwd_kernel(const float *__r
     int b, ty0, tx0, d0, d1;
     c16_item(dm, blockIdx.x, b, ty0, tx0, d0, d1);
     const size_t plane = (size_t)dm.H * dm.W;
-    const float4 *inb = reinterpret_cast<const float4 *>(in) + (size_t)b * dm.D * plane * 4;
+    const float *inb = in + (size_t)b * dm.D * plane * CI;
     float *outb = out + (size_t)b * dm.D * plane * CO;
     f32x4 wr[NTAP];  // wr[tap][s] = wt(n, kk*4+s, tap)
 #pragma unroll
@@ -182,26 +230,10 @@ __global__ __launch_bounds__(256, 2) void conv3d_c16_fwd_kernel(const float *__r
         const float *p = wt + n * s_n + (long long)(kk * 4) * s_m + (mirror ? 26 - k : k) * s_k;
         wr[k] = (f32x4){p[0], p[s_m], p[2 * s_m], p[3 * s_m]};
     }
-    int lofs[NLD];
-#pragma unroll
-    for (int i = 0; i < NLD; ++i) {
-        const int idx = tid + i * 256, cell = idx >> 2, qq = idx & 3;
-        const int yy = ty0 - 1 + cell / HW_, xx = tx0 - 1 + cell % HW_;
-        lofs[i] = (idx < CELLS * 4 && yy >= 0 && yy < dm.H && xx >= 0 && xx < dm.W) ? (yy * dm.W + xx) * 4 + qq : -1;
-    }
-    float4 pre[NLD];
-    auto fetch = [&](int P) {
-        const bool inr = P >= 0 && P < dm.D;
-#pragma unroll
-        for (int i = 0; i < NLD; ++i)
-            pre[i] = (inr && lofs[i] >= 0) ? inb[(size_t)P * plane * 4 + lofs[i]] : make_float4(0.f, 0.f, 0.f, 0.f);
-    };
-    auto stash = [&](int P) {
-        float4 *slot = reinterpret_cast<float4 *>(ring + ((P + 3) % 3) * PLANE_F);
-#pragma unroll
-        for (int i = 0; i < NLD; ++i)
-            if (tid + i * 256 < CELLS * 4) slot[tid + i * 256] = pre[i];
-    };
+    Stager<IN_PLANAR> st;
+    st.init(dm, ty0, tx0);
+    auto fetch = [&](int P) { st.fetch(inb, dm, P); };
+    auto stash = [&](int P) { st.stash(ring + ((P + 3) % 3) * PLANE_F); };
     fetch(d0 - 1); stash(d0 - 1);
     fetch(d0);     stash(d0);
     fetch(d0 + 1);
@@ -209,36 +241,59 @@ __global__ __launch_bounds__(256, 2) void conv3d_c16_fwd_kernel(const float *__r
         stash(d + 1);
         __syncthreads();
         if (d + 1 < d1) fetch(d + 2);
-        const float4 *s0 = reinterpret_cast<const float4 *>(ring + ((d + 2) % 3) * PLANE_F) + kk;  // planes d-1, d, d+1
-        const float4 *s1 = reinterpret_cast<const float4 *>(ring + (d % 3) * PLANE_F) + kk;
-        const float4 *s2 = reinterpret_cast<const float4 *>(ring + ((d + 1) % 3) * PLANE_F) + kk;
+        const float *s0 = ring + ((d + 2) % 3) * PLANE_F;  // planes d-1, d, d+1
+        const float *s1 = ring + (d % 3) * PLANE_F;
+        const float *s2 = ring + ((d + 1) % 3) * PLANE_F;
 #pragma unroll 1
         for (int g = 0; g < 4; ++g) {  // group = tile row 2*wave + g/2, columns (g%2)*16 .. +15
             const int row = 2 * wave + (g >> 1), col0 = (g & 1) * 16;
-            const int cell = (row * HW_ + col0 + n) * 4;  // lane's voxel (n doubles as the voxel index for A), halo origin
+            const int cell = row * HW_ + col0 + n;  // this lane's voxel (n doubles as the voxel index), halo origin
             f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc;  // two chains: a dependent MFMA issues 8 cycles later
 #pragma unroll
             for (int kd = 0; kd < 3; ++kd) {
-                const float4 *sl = (kd == 0 ? s0 : kd == 1 ? s1 : s2) + cell;
+                const float *sl = (kd == 0 ? s0 : kd == 1 ? s1 : s2);
 #pragma unroll
                 for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
                     for (int kw = 0; kw < 3; ++kw) {
-                        const float4 a = sl[(kh * HW_ + kw) * 4];
+                        float4 a;  // channels kk*4 .. kk*4+3 of the tap-shifted voxel
+                        const int c = cell + kh * HW_ + kw;
+                        if (IN_PLANAR) {
+                            const float *pc = sl + (kk * 4) * CELLS + c;
+                            a = make_float4(pc[0], pc[CELLS], pc[2 * CELLS], pc[3 * CELLS]);
+                        } else {
+                            a = reinterpret_cast<const float4 *>(sl)[c * 4 + kk];
+                        }
                         const f32x4 w4 = wr[(kd * 3 + kh) * 3 + kw];
-                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w4[0], acc, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w4[1], acc1, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, w4[2], acc, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, w4[3], acc1, 0, 0, 0);
+                        if (OUT_PLANAR) {  // D[n][voxel]: weights as A, input as B
+                            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[0], a.x, acc, 0, 0, 0);
+                            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[1], a.y, acc1, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[2], a.z, acc, 0, 0, 0);
+                            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[3], a.w, acc1, 0, 0, 0);
+                        } else {           // D[voxel][n]
+                            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w4[0], acc, 0, 0, 0);
+                            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w4[1], acc1, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, w4[2], acc, 0, 0, 0);
+                            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, w4[3], acc1, 0, 0, 0);
+                        }
                     }
             }
             acc += acc1;
-            // D layout: register r of lane l = out[voxel 4*(l>>4) + r][n = l&15]
             const int yy = ty0 + row;
+            if (OUT_PLANAR) {
+                // register r of lane l = out[channel 4*(l>>4) + r][voxel l&15]: 64 contiguous bytes per channel
+                const int xx = tx0 + col0 + n;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int xx = tx0 + col0 + 4 * kk + r;
-                if (yy < dm.H && xx < dm.W) outb[((size_t)d * plane + (size_t)yy * dm.W + xx) * CO + n] = acc[r];
+                for (int r = 0; r < 4; ++r)
+                    if (yy < dm.H && xx < dm.W)
+                        outb[((size_t)(4 * kk + r) * dm.D + d) * plane + (size_t)yy * dm.W + xx] = acc[r];
+            } else {
+                // register r of lane l = out[voxel 4*(l>>4) + r][channel l&15]
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int xx = tx0 + col0 + 4 * kk + r;
+                    if (yy < dm.H && xx < dm.W) outb[((size_t)d * plane + (size_t)yy * dm.W + xx) * CO + n] = acc[r];
+                }
             }
         }
         __syncthreads();
@@ -265,26 +320,33 @@ int c16_dims(const char *fn, int B, int Ci, int Co, int D, int H, int W, C16Dims
 extern "C" {
 
 static int c16_launch_fwd(const char *fn, const float *in, const float *wt, long long s_n, long long s_m, long long s_k, int mirror,
-                          float *out, int B, int Ci, int Co, int D, int H, int W, md_stream_t stream) {
+                          int in_planar, int out_planar, float *out, int B, int Ci, int Co, int D, int H, int W,
+                          md_stream_t stream) {
     MD_REQUIRE(in && wt && out, "%s: null tensor argument", fn);
-    MD_REQUIRE(((uintptr_t)in % 16) == 0, "%s: the input volume must be 16-byte aligned", fn);
+    MD_REQUIRE(in_planar || ((uintptr_t)in % 16) == 0, "%s: a channels-last input volume must be 16-byte aligned", fn);
     C16Dims dm;
     if (int rc = c16_dims(fn, B, Ci, Co, D, H, W, dm)) return rc;
-    hipLaunchKernelGGL(conv3d_c16_fwd_kernel, dim3(B * dm.tiles * dm.dslices), dim3(256), 0, (hipStream_t)stream, in, wt, s_n,
-                       s_m, s_k, mirror, out, dm);
+    const dim3 grid(B * dm.tiles * dm.dslices), block(256);
+    hipStream_t s = (hipStream_t)stream;
+#define MD_C16_FWD(IP, OP) hipLaunchKernelGGL((conv3d_c16_fwd_kernel<IP, OP>), grid, block, 0, s, in, wt, s_n, s_m, s_k, mirror, out, dm)
+    if (in_planar) { if (out_planar) MD_C16_FWD(true, true); else MD_C16_FWD(true, false); }
+    else { if (out_planar) MD_C16_FWD(false, true); else MD_C16_FWD(false, false); }
+#undef MD_C16_FWD
     MD_CHECK_LAUNCH(fn);
     return MD_OK;
 }
 
-int md_conv3d_c16_fwd(const float *x, const float *wt, long long w_stride_co, long long w_stride_ci, long long w_stride_k,
-                      float *y, int B, int Ci, int Co, int D, int H, int W, md_stream_t stream) {
-    return c16_launch_fwd("md_conv3d_c16_fwd", x, wt, w_stride_co, w_stride_ci, w_stride_k, 0, y, B, Ci, Co, D, H, W, stream);
+int md_conv3d_c16_fwd(const float *x, int x_planar, const float *wt, long long w_stride_co, long long w_stride_ci,
+                      long long w_stride_k, float *y, int B, int Ci, int Co, int D, int H, int W, md_stream_t stream) {
+    return c16_launch_fwd("md_conv3d_c16_fwd", x, wt, w_stride_co, w_stride_ci, w_stride_k, 0, x_planar, 0, y, B, Ci, Co, D, H,
+                          W, stream);
 }
 
 int md_conv3d_c16_bwd_data(const float *gy, const float *wt, long long w_stride_co, long long w_stride_ci,
-                           long long w_stride_k, float *dx, int B, int Ci, int Co, int D, int H, int W, md_stream_t stream) {
-    return c16_launch_fwd("md_conv3d_c16_bwd_data", gy, wt, w_stride_ci, w_stride_co, w_stride_k, 1, dx, B, Ci, Co, D, H, W,
-                          stream);
+                           long long w_stride_k, float *dx, int dx_planar, int B, int Ci, int Co, int D, int H, int W,
+                           md_stream_t stream) {
+    return c16_launch_fwd("md_conv3d_c16_bwd_data", gy, wt, w_stride_ci, w_stride_co, w_stride_k, 1, 0, dx_planar, dx, B, Ci, Co,
+                          D, H, W, stream);
 }
 
 size_t md_conv3d_c16_bwd_weight_ws_bytes(int B, int D, int H, int W) {
@@ -293,18 +355,20 @@ size_t md_conv3d_c16_bwd_weight_ws_bytes(int B, int D, int H, int W) {
     return (size_t)B * dm.tiles * dm.dslices * NTAP * CI * CO * sizeof(float);
 }
 
-int md_conv3d_c16_bwd_weight(const float *x, const float *gy, float *dwt, long long dw_stride_co, long long dw_stride_ci,
-                             long long dw_stride_k, void *ws, size_t ws_bytes, int B, int Ci, int Co, int D, int H, int W,
-                             md_stream_t stream) {
+int md_conv3d_c16_bwd_weight(const float *x, int x_planar, const float *gy, float *dwt, long long dw_stride_co,
+                             long long dw_stride_ci, long long dw_stride_k, void *ws, size_t ws_bytes, int B, int Ci, int Co,
+                             int D, int H, int W, md_stream_t stream) {
     MD_REQUIRE(x && gy && dwt && ws, "md_conv3d_c16_bwd_weight: null tensor argument");
-    MD_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)ws % 16) == 0, "md_conv3d_c16_bwd_weight: x and ws must be 16-byte aligned");
+    MD_REQUIRE((x_planar || ((uintptr_t)x % 16) == 0) && ((uintptr_t)ws % 16) == 0,
+               "md_conv3d_c16_bwd_weight: a channels-last x and ws must be 16-byte aligned");
     C16Dims dm;
     if (int rc = c16_dims("md_conv3d_c16_bwd_weight", B, Ci, Co, D, H, W, dm)) return rc;
     const int nwg = B * dm.tiles * dm.dslices;
     MD_REQUIRE(ws_bytes >= (size_t)nwg * NTAP * CI * CO * sizeof(float), "md_conv3d_c16_bwd_weight: workspace too small (%zu bytes)", ws_bytes);
     hipStream_t s = (hipStream_t)stream;
     float *partial = (float *)ws;
-    hipLaunchKernelGGL(conv3d_c16_bwd_weight_kernel, dim3(nwg), dim3(256), 0, s, x, gy, partial, dm);
+    if (x_planar) hipLaunchKernelGGL(conv3d_c16_bwd_weight_kernel<true>, dim3(nwg), dim3(256), 0, s, x, gy, partial, dm);
+    else hipLaunchKernelGGL(conv3d_c16_bwd_weight_kernel<false>, dim3(nwg), dim3(256), 0, s, x, gy, partial, dm);
     MD_CHECK_LAUNCH("md_conv3d_c16_bwd_weight");
     hipLaunchKernelGGL(conv3d_c16_bwd_weight_finish_kernel, dim3(NTAP * 256 / 64), dim3(256), 0, s, partial, nwg, dw_stride_co,
                        dw_stride_ci, dw_stride_k, dwt);

@@ -367,11 +367,14 @@ class reg3d(nn.Module):
         # written that way (ops.costvol_grouped(layout='ndhwc'))
         cl = self.conv0.conv.weight.is_contiguous(memory_format=torch.channels_last_3d) and \
             not self.conv0.conv.weight.is_contiguous()
-        x = x.contiguous(memory_format=torch.channels_last_3d) if cl else x.contiguous()
         if cl and x.is_cuda and self.hip_conv0_wgrad and tuple(self.conv0.conv.weight.shape) == (16, 16, 3, 3, 3):
-            # first layer on the MFMA kernels (library: 1.0 / 1.4 / 3.1 ms fwd / data gradient / weight gradient)
+            # first layer on the MFMA kernels (library: 1.0 / 1.4 / 3.1 ms fwd / data gradient / weight gradient); they
+            # read a planar (`bgd`) or a channels-last volume in place and hand the gradient back in the same layout
+            if not (x.is_contiguous() or x.is_contiguous(memory_format=torch.channels_last_3d)):
+                x = x.contiguous(memory_format=torch.channels_last_3d)
             c0 = F.relu(self.conv0.bn(ops.conv3d_16(x, self.conv0.conv.weight, self.lib_conv0_fwd_dgrad)), inplace=True)
         else:
+            x = x.contiguous(memory_format=torch.channels_last_3d) if cl else x.contiguous()
             c0 = self.conv0(x)
         c2 = self.conv2(self.conv1(c0))
         if self.down_size >= 2:

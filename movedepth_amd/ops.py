@@ -514,21 +514,32 @@ def _c16_weight_strides(w):
     return s[0], s[1], s[4]
 
 
+def _is_planar(t):
+    """plain contiguous [B,C,D,H,W] (the cost volume's `bgd` storage) as opposed to channels_last_3d"""
+    return t.is_contiguous() and not t.is_contiguous(memory_format=torch.channels_last_3d)
+
+
 class _Conv3d16(torch.autograd.Function):
-    """reg3d.conv0's convolution on the MFMA kernels of csrc/conv3d_c16.hip.  `lib_fwd_dgrad` keeps the forward and the
-    data gradient on the library convolution (A/B switch; the weight gradient is always the hand-written one)."""
+    """reg3d.conv0's convolution on the MFMA kernels of csrc/conv3d_c16.hip.  x may be planar (contiguous
+    [B,16,D,H,W], what md_costvol_fwd writes fastest) or channels_last_3d; y is channels_last_3d; dx has x's layout.
+    `lib_fwd_dgrad` keeps the forward and the data gradient on the library convolution (A/B switch; the weight
+    gradient is always the hand-written one)."""
 
     @staticmethod
     def forward(ctx, x, weight, lib_fwd_dgrad):
-        x = x.contiguous(memory_format=torch.channels_last_3d)
-        ctx.save_for_backward(x, weight)
         ctx.lib = bool(lib_fwd_dgrad)
+        planar = _is_planar(x) and not ctx.lib
+        if not planar:
+            x = x.contiguous(memory_format=torch.channels_last_3d)
+        ctx.planar = planar
+        ctx.save_for_backward(x, weight)
         if ctx.lib:
             return torch.ops.aten.convolution(x, weight, None, *_CONV_ARGS)
         B, C, D, H, W = x.shape
-        y = torch.empty_like(x, memory_format=torch.channels_last_3d)
-        _timed_call("md_conv3d_c16_fwd", _p(x), _p(weight), *_c16_weight_strides(weight), _p(y), B, C, weight.shape[0], D, H, W,
-                    _stream())
+        y = torch.empty((B, weight.shape[0], D, H, W), device=x.device, dtype=torch.float32,
+                        memory_format=torch.channels_last_3d)
+        _timed_call("md_conv3d_c16_fwd", _p(x), int(planar), _p(weight), *_c16_weight_strides(weight), _p(y), B, C,
+                    weight.shape[0], D, H, W, _stream())
         return y
 
     @staticmethod
@@ -541,22 +552,22 @@ class _Conv3d16(torch.autograd.Function):
             if ctx.lib:
                 dx = torch.ops.aten.convolution_backward(gy, x, weight, None, *_CONV_ARGS, [True, False, False])[0]
             else:
-                dx = torch.empty_like(x, memory_format=torch.channels_last_3d)
-                _timed_call("md_conv3d_c16_bwd_data", _p(gy), _p(weight), *_c16_weight_strides(weight), _p(dx), B, C,
-                            weight.shape[0], D, H, W, _stream())
+                dx = torch.empty_like(x, memory_format=torch.contiguous_format if ctx.planar else torch.channels_last_3d)
+                _timed_call("md_conv3d_c16_bwd_data", _p(gy), _p(weight), *_c16_weight_strides(weight), _p(dx),
+                            int(ctx.planar), B, C, weight.shape[0], D, H, W, _stream())
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(weight)  # keeps the weight's strides
             nbytes = _lib.load().md_conv3d_c16_bwd_weight_ws_bytes(B, D, H, W)
             ws = _ws(nbytes, x.device)
-            _timed_call("md_conv3d_c16_bwd_weight", _p(x), _p(gy), _p(dw), *_c16_weight_strides(dw), _p(ws), int(nbytes), B, C,
-                        weight.shape[0], D, H, W, _stream())
+            _timed_call("md_conv3d_c16_bwd_weight", _p(x), int(ctx.planar), _p(gy), _p(dw), *_c16_weight_strides(dw), _p(ws),
+                        int(nbytes), B, C, weight.shape[0], D, H, W, _stream())
         return dx, dw, None
 
 
 def conv3d_16(x, weight, lib_fwd_dgrad=False):
     """nn.Conv3d(16, 16, 3, stride=1, padding=1, bias=False) -- reg3d.conv0's convolution (reference
-    networks/resnet_encoder.py:231,258).  x (B,16,D,H,W) on the GPU, read as channels_last_3d; weight (16,16,3,3,3) in
-    either memory format; returns a channels_last_3d (B,16,D,H,W) tensor."""
+    networks/resnet_encoder.py:231,258).  x (B,16,D,H,W) on the GPU, planar (contiguous) or channels_last_3d, read in
+    place; weight (16,16,3,3,3) in either memory format; returns a channels_last_3d (B,16,D,H,W) tensor."""
     if not x.is_cuda or tuple(weight.shape) != (16, 16, 3, 3, 3) or x.shape[1] != 16:
         raise _lib.MovedepthHipError("conv3d_16: needs a GPU tensor with 16 channels and a (16,16,3,3,3) weight, got %s %s %s"
                                      % (x.device, tuple(x.shape), tuple(weight.shape)))

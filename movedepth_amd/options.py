@@ -85,6 +85,9 @@ class MonodepthOptions:
         p.add_argument("--hip_conv0", default="all", choices=["all", "wgrad", "none"],
                        help="the 3-D regulariser's first convolution on the MFMA kernels: all three directions, the "
                             "weight gradient only, or none (library)")
+        p.add_argument("--vol_layout", default="auto", choices=["auto", "bgd", "ndhwc"],
+                       help="storage of the grouped cost volume: planar (B,G,D,h,w) or channels-last (B,D,h,w,G); auto = "
+                            "channels-last when the 3-D regulariser runs channels-last (measured fastest), else planar")
         p.add_argument("--fused_adam", type=int, default=1, help="torch's fused Adam kernel on the GPU (0: default implementation)")
         p.add_argument("--sync_bn", type=int, default=1, help="with --ddp: convert BatchNorm to SyncBatchNorm (reference)")
         p.add_argument("--grad_bucket_mb", type=float, default=32.0, help="with --ddp: all-reduce bucket size")

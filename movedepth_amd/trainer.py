@@ -87,7 +87,13 @@ class Trainer:
         self.vol_layout = "bgd"
         if opt.reg3d_channels_last and opt.num_depth_bins >= 8:
             self.models["reg3d"] = self.models["reg3d"].to(memory_format=torch.channels_last_3d)
+            # channels-last volume (B,D,h,w,G).  The hand-written first layer can also read the planar volume in place
+            # (--vol_layout bgd), but that measured 0.6 ms per step slower: its planar-input weight gradient and
+            # forward cost +245 / +104 us, the plane-sweep backward gains 52 us, and the planar plane-sweep forward is
+            # no faster inside the step (76-78 us) than the channels-last one (75 us) -- DESIGN.md 4.3
             self.vol_layout = "ndhwc"
+        if opt.vol_layout != "auto":
+            self.vol_layout = opt.vol_layout
         for k, m in self.models.items():
             if opt.ddp and opt.sync_bn and not share_gpu:
                 m = torch.nn.SyncBatchNorm.convert_sync_batchnorm(m)

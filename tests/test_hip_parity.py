@@ -548,17 +548,22 @@ def test_conv0_golden(ops, weight_cl, lib_fwd_dgrad):
     (3, 1, 5, 3),      # a single plane smaller than the halo
     (1, 2, 1, 1),      # one voxel column
 ])
-def test_conv0_vs_oracle(ops, oracle_lib, shape):
+@pytest.mark.parametrize("planar", [False, True])
+def test_conv0_vs_oracle(ops, oracle_lib, shape, planar):
+    """planar: x is the cost volume's `bgd` storage (contiguous [B,16,D,H,W]), read in place; dx comes back planar."""
     rng = np.random.default_rng(31)
     B, D, H, W = shape
     x = rng.standard_normal((B, 16, D, H, W)).astype(np.float32)
     wt = (rng.standard_normal((16, 16, 3, 3, 3)) * 0.1).astype(np.float32)
     gy = rng.standard_normal((B, 16, D, H, W)).astype(np.float32)
     exp_y, exp_dx, exp_dw = oracle_lib.conv3d(x, wt, gy)
-    xt, wtt = _cl3d(dev(x)).requires_grad_(True), dev(wt, True)
+    xt = (dev(x) if planar else _cl3d(dev(x))).requires_grad_(True)
+    wtt = dev(wt, True)
     y = ops.conv3d_16(xt, wtt)
+    assert y.is_contiguous(memory_format=torch.channels_last_3d)
     assert_close(host(y), exp_y, what="y")
     dx, dw = torch.autograd.grad(y, (xt, wtt), _cl3d(dev(gy)))
+    assert dx.stride() == xt.stride(), "the data gradient must come back in x's layout"
     assert_close(host(dx), exp_dx, what="d_x")
     assert_close(host(dw), exp_dw, what="d_weight")
 
@@ -581,6 +586,14 @@ def test_conv0_full_size_vs_library(ops):
     assert_close(host(dw), host(dw_ref), what="d_weight vs library")
     lhs, rhs = (y.detach().double() * gy.double()).sum().item(), (x.detach().double() * dx.double()).sum().item()
     assert abs(lhs - rhs) <= 1e-5 * max(abs(lhs), abs(rhs), 1.0), "forward and data gradient are not adjoint: %r %r" % (lhs, rhs)
+    # the same volume in planar storage must give the same three results (different kernels: LDS layout, operand roles)
+    xp = x.detach().contiguous().requires_grad_(True)
+    yp = ops.conv3d_16(xp, w)
+    dxp, dwp = torch.autograd.grad(yp, (xp, w), gy)
+    assert dxp.is_contiguous()
+    assert_close(host(yp), host(y_ref), what="y (planar x) vs library")
+    assert_close(host(dxp), host(dx_ref), what="d_x (planar) vs library")
+    assert_close(host(dwp), host(dw_ref), what="d_weight (planar x) vs library")
     (dw2,) = torch.autograd.grad(y, w, gy, retain_graph=True)
     assert torch.equal(dw, dw2), "weight gradient must be bit-reproducible"
     gy2 = _cl3d(torch.randn_like(gy))
@@ -589,19 +602,53 @@ def test_conv0_full_size_vs_library(ops):
     assert_close(host(dw_lin), host(dw + 0.5 * dw_b), what="linearity in gy")
 
 
-def test_reg3d_conv0_paths_agree(ops):
+def _reg3d_run(net, vol):
+    """forward + backward of reg3d; returns (logits, d_volume, d_conv0_weight) and the ReLU masks (sign of every
+    BatchNorm output)."""
+    masks, hooks = [], []
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm3d):
+            hooks.append(m.register_forward_hook(lambda mod, i, o: masks.append((o.detach() > 0).cpu())))
+    net.zero_grad()
+    v = vol.detach().requires_grad_(True)  # keeps the strides
+    o = net(v)
+    for hk in hooks:
+        hk.remove()
+    o.square().mean().backward()
+    return (host(o), host(v.grad), host(net.conv0.conv.weight.grad)), masks
+
+
+@pytest.mark.parametrize("vol_layout", ["bdg", "bgd", "ndhwc"])
+def test_reg3d_conv0_paths_agree(ops, vol_layout):
+    """reg3d fed with the volume in each storage the cost-volume kernel can write: same logits and gradients whether
+    its first convolution runs on the MFMA kernels (in place on that storage) or on the library.
+
+    Gradients through 11 ReLUs are only comparable at 1e-4 when both runs take the same side of every ReLU: one
+    pre-activation within fp32 rounding of zero (expected about once per run at these sizes; measured with seed 4 /
+    layout bgd: one element of 393,216 at 2e-6 against a layer rms of 1, flipped in the LIBRARY run relative to an
+    fp64 copy of the network, tools/diag_reg3d_paths.py) changes the whole volume gradient by ~5e-4 norm-wise.  So:
+    logits always at 1e-4; gradients at 1e-4 when the masks agree, at 5e-3 and with at most 3 flipped elements
+    otherwise."""
     from movedepth_amd import networks
     torch.manual_seed(4)
     net = networks.reg3d(16, 16, 3).cuda().to(memory_format=torch.channels_last_3d)
-    vol = torch.randn(2, 16, 16, 24, 32, device="cuda")
-    outs = []
+    B, D, G, h, w = 2, 16, 16, 24, 32
+    if vol_layout == "bdg":
+        vol = torch.randn(B, D, G, h, w, device="cuda")
+    elif vol_layout == "bgd":
+        vol = torch.randn(B, G, D, h, w, device="cuda").permute(0, 2, 1, 3, 4)
+    else:
+        vol = torch.randn(B, D, h, w, G, device="cuda").permute(0, 1, 4, 2, 3)
+    runs = []
     for hip, lib_fd in ((True, False), (True, True), (False, False)):
         net.hip_conv0_wgrad, net.lib_conv0_fwd_dgrad = hip, lib_fd
-        net.zero_grad()
-        v = vol.clone().requires_grad_(True)
-        o = net(v)
-        o.square().mean().backward()
-        outs.append((host(o), host(v.grad), host(net.conv0.conv.weight.grad)))
-    for other in outs[:2]:
-        for a, b, what in zip(other, outs[2], ("logits", "d_volume", "d_conv0_weight")):
-            assert_close(a, b, what=what)
+        runs.append(_reg3d_run(net, vol))
+    ref_out, ref_masks = runs[2]
+    for out, masks in runs[:2]:
+        flips = sum(int((a != b).sum()) for a, b in zip(masks, ref_masks))
+        assert flips <= 3, "%d ReLU decisions differ between the two conv0 implementations" % flips
+        assert_close(out[0], ref_out[0], what="logits")
+        for a, b, what in zip(out[1:], ref_out[1:], ("d_volume", "d_conv0_weight")):
+            assert_close(a, b, rtol=1e-4 if flips == 0 else 5e-3, what="%s (%d ReLU flips)" % (what, flips))
+
+
