@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import assert_close, assert_close_knife_edge, load_golden
+from conftest import relerr, assert_close, assert_close_knife_edge, load_golden
 
 pytestmark = pytest.mark.gpu
 
@@ -218,3 +218,48 @@ def test_process_batch_three_lookup_frames_and_flags():
     for name, m in t.models.items():
         for pn, p in m.named_parameters():
             assert p.grad is not None and torch.isfinite(p.grad).all(), (name, pn)
+
+
+def test_channels_last_2d_networks_give_the_same_step():
+    """--nets2d_channels_last only changes the memory format of the 2-D networks' weights/activations (and with it
+    the library kernels picked): same parameters and inputs must give the same forward results.  Forward quantities
+    only -- gradients through dozens of ReLUs are not comparable at 1e-4 across convolution algorithms (see
+    test_reg3d_conv0_paths_agree in test_hip_parity.py)."""
+    from movedepth_amd.options import MovedepthOptions
+    from movedepth_amd.synthetic import make_inputs
+    from movedepth_amd.trainer import Trainer
+
+    res = []
+    for flag in ("0", "1"):
+        opt = MovedepthOptions().parse(["--height", "64", "--width", "128", "--num_depth_bins", "16", "--batch_size", "2",
+                                        "--convex_up", "--weights_init", "scratch", "--miopen_find", "0",
+                                        "--automask_noise", "host", "--nets2d_channels_last", flag])
+        torch.manual_seed(0)
+        np.random.seed(0)
+        t = Trainer(opt)
+        t.set_train()
+        inputs = make_inputs(2, 64, 128, opt.frame_ids, seed=0, device=t.device)
+        torch.manual_seed(1)
+        np.random.seed(1)
+        outputs, losses = t.process_batch(inputs, is_train=True)
+        losses["loss"].backward()
+        gn = torch.sqrt(sum((p.grad.double() ** 2).sum() for m in t.models.values() for p in m.parameters() if p.grad is not None))
+        res.append(({k: float(v) for k, v in losses.items() if torch.is_tensor(v) and v.numel() == 1},
+                    host(outputs[("disp", 0)]), host(outputs["depth_mvs"]), float(gn)))
+    a, b = res
+    report = {k: abs(a[0][k] - b[0][k]) / max(abs(a[0][k]), 1e-12) for k in a[0]}
+    report["disp"], report["depth_mvs"], report["grad_norm"] = relerr(b[1], a[1]), relerr(b[2], a[2]), abs(a[3] - b[3]) / a[3]
+    print("channels_last vs default, relative differences:", {k: "%.2e" % v for k, v in report.items()})
+    # continuous network outputs must agree to rounding (measured 5e-8 / 1e-7): a layout mix-up would show here
+    assert_close(b[1], a[1], rtol=1e-5, what="disp")
+    assert_close(b[2], a[2], rtol=1e-4, what="depth_mvs")      # through reg3d + softmax over 16 hypotheses
+    # losses without per-pixel decisions: smoothness, masked-consistency, fused-depth L1
+    for k in a[0]:
+        if "smooth" in k or k in ("masked_loss", "fuse_reproj_loss"):
+            assert report[k] <= 1e-5, (k, a[0][k], b[0][k])
+    # the photometric losses take a min over frames and an auto-mask argmin per pixel; with outputs equal to 1e-7 they
+    # were still seen to differ by 2-3e-4 at a single scale, a different scale in each of two invocations.  Sanity bound
+    # only; parity of these losses against the reference is pinned by the golden-fixture tests above.
+    for k in a[0]:
+        assert report[k] <= 1e-3, (k, a[0][k], b[0][k])
+    assert report["grad_norm"] <= 2e-2, ("gradient norm", a[3], b[3])
