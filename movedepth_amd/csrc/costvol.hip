@@ -677,7 +677,7 @@ int launch(const CvPtrs &q, CvDims dm, hipStream_t stream) {
         nwg = (long long)dm.items * dsplit;
         // Channels-last forward only: LDS allows 2 workgroups per CU, and item-aligned slices rarely fill the slots
         // evenly (B=6, 48x160: 360 workgroups on 512 slots, so 104 CUs carry two and 152 carry one).  A linear
-        // split over exactly `slots` workgroups measured 70.2 us against 74.5 us (medians of 8 interleaved runs,
+        // split over exactly `slots` workgroups measured 70.2 us against 74.5 us (same-buffer medians of 8 interleaved runs,
         // 7 of 8 pairs faster) despite ~1/3 of the workgroups staging two windows.  The planar kernels measured
         // the opposite (72 vs 60 us) and keep item-aligned slices.
         if (cl_out && nwg < slots && total >= slots * 8 && env_int("MD_COSTVOL_CL_FILL", 1)) nwg = slots;

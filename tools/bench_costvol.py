@@ -35,6 +35,9 @@ def main():
     ap.add_argument("--fused", type=int, default=1)
     ap.add_argument("--layout", default="bgd")
     ap.add_argument("--iters", type=int, default=50)
+    ap.add_argument("--rotate", type=int, default=8,
+                    help="write into N different output buffers in turn (N x 283 MB >> the 256 MB Infinity Cache), so that a "
+                         "launch cannot benefit from lines of its own output left in cache by the previous launch")
     a = ap.parse_args()
     B, h, w, D, C, G = a.B, a.h, a.w, a.D, a.C, a.G
     torch.manual_seed(0)
@@ -51,9 +54,18 @@ def main():
     vol = ops.costvol_grouped(ref, src, K, invK, pose, G, layout=a.layout, **kw)
     g = torch.randn_like(vol)
 
+    keep = [None] * max(a.rotate - 1, 0)
+    cnt = [0]
+
     def fwd():
         with torch.no_grad():
-            ops.costvol_grouped(ref, src, K, invK, pose, G, layout=a.layout, **kw)
+            # rotate=1: the result is dropped at once, the caching allocator hands the same block to every launch (the
+            # first version of this script always did that).  rotate=N: the last N-1 results stay alive while the next
+            # one is allocated, so N distinct blocks are written in turn.
+            out = ops.costvol_grouped(ref, src, K, invK, pose, G, layout=a.layout, **kw)
+            if keep:
+                keep[cnt[0] % len(keep)] = out
+                cnt[0] += 1
 
     def bwd():
         vol.backward(g, retain_graph=True)
@@ -61,12 +73,20 @@ def main():
     hyp_bytes = 4 * B * h * w if a.fused else 4 * B * D * h * w
     fbytes = 2 * 4 * B * C * h * w + hyp_bytes + 4 * B * D * G * h * w + 192 * B
     bbytes = 4 * B * D * G * h * w + 2 * 4 * B * C * h * w + hyp_bytes + 2 * 4 * B * C * h * w
-    big = torch.empty_like(vol.contiguous())
-    t_fill = time_fn(lambda: big.zero_(), a.iters)
+    bigs = [torch.empty_like(vol.contiguous()) for _ in range(max(a.rotate, 1))]
+    big = bigs[0]
+    zc = [0]
+
+    def fill():
+        bigs[zc[0] % len(bigs)].zero_()
+        zc[0] += 1
+
+    t_fill = time_fn(fill, a.iters)
     src_big = torch.randn_like(big)
     t_copy = time_fn(lambda: big.copy_(src_big), a.iters)
-    print("  ref: zero_ of %.0f MB %.1f us (%.0f GB/s); copy_ %.1f us (%.0f GB/s r+w)" % (
-        big.numel() * 4 / 1e6, t_fill, big.numel() * 4 / t_fill / 1e3, t_copy, 2 * big.numel() * 4 / t_copy / 1e3))
+    print("  ref (rotate=%d): zero_ of %.0f MB %.1f us (%.0f GB/s); copy_ (one buffer pair) %.1f us (%.0f GB/s r+w)" % (
+        len(bigs), big.numel() * 4 / 1e6, t_fill, big.numel() * 4 / t_fill / 1e3, t_copy, 2 * big.numel() * 4 / t_copy / 1e3))
+    del bigs
     tf = time_fn(fwd, a.iters)
     tb = time_fn(bwd, a.iters)
     env = {k: v for k, v in os.environ.items() if k.startswith("MD_")}
