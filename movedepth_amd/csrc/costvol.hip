@@ -499,6 +499,7 @@ __global__ __launch_bounds__(256) void costvol_fwd_nhwc_kernel(const float *__re
 #pragma unroll
         for (int k = 0; k < NCH; ++k) {
             const float4 v = my_stage[sidx[k]];
+            // (nontemporal stores measured the same, cold output: 76.8 / 77.1 / 76.8 us against 76.7 / 77.1 / 77.3)
             if (soff[k] >= 0) *reinterpret_cast<float4 *>(out + soff[k] + (long long)(d - d0) * dm.sd) = v;
         }
         __builtin_amdgcn_wave_barrier();
