@@ -68,6 +68,11 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch first: its wheel bundles its own HIP runtime; if libmovedepth_hip.so is loaded before torch, the process
+    # ends up with two runtimes and kernel launches from this library fail with "no ROCm-capable device is detected"
+    # (seen with __graft_entry__.build() followed by smoke() in one process)
+    import torch  # noqa: F401
+
     if not os.path.exists(LIB_PATH):
         raise MovedepthHipError(
             "libmovedepth_hip.so not found at %s: the HIP extension is required (no CPU fallback). "
