@@ -83,14 +83,22 @@ int mm_blocks(int total) {
 // ------------------------------------------------------------------ smoothness
 constexpr int SM_BLK = 64;  // blocks per sample for the pixel passes
 
-// workspace layout (floats): mean[B] | part[B*SM_BLK*2] | dots[B*SM_BLK]
-__global__ __launch_bounds__(256) void smooth_mean_kernel(const float *__restrict__ disp, int hw, float *__restrict__ ws) {
+// workspace layout (floats): (unused)[B] | part[B*SM_BLK*2] | dots[B*SM_BLK] | msum[B*SM_BLK]
+// Mean of each sample's disparity, stage 1: SM_BLK partial sums per sample.  (One block per sample, as this was at
+// first, is 480 dependent loads per thread at 192x640: 186 us for a 0.5 MB reduction.)  Stage 2 is sample_mean() at the
+// top of each consumer, always the same fixed-order sum, so forward and backward see the identical mean.
+__global__ __launch_bounds__(256) void smooth_mean_kernel(const float *__restrict__ disp, int hw, int B, float *__restrict__ ws) {
     __shared__ float red[4];
-    const int b = blockIdx.x;
+    const int b = blockIdx.y;
     float s = 0.f;
-    for (int p = threadIdx.x; p < hw; p += 256) s += disp[(size_t)b * hw + p];
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < hw; p += SM_BLK * 256) s += disp[(size_t)b * hw + p];
     s = block_sum(s, red);
-    if (threadIdx.x == 0) ws[b] = s / (float)hw;
+    if (threadIdx.x == 0) ws[B + (size_t)B * SM_BLK * 3 + (size_t)b * SM_BLK + blockIdx.x] = s;
+}
+
+__device__ __forceinline__ float sample_mean(const float *__restrict__ ws, int B, int b, int hw, float *red) {
+    const float s = threadIdx.x < SM_BLK ? ws[B + (size_t)B * SM_BLK * 3 + (size_t)b * SM_BLK + threadIdx.x] : 0.f;
+    return block_sum(s, red) / (float)hw;
 }
 
 __device__ __forceinline__ float edge_w(const float *__restrict__ img, int Ci, size_t hw, size_t p, size_t q) {
@@ -103,7 +111,7 @@ __global__ __launch_bounds__(256) void smooth_fwd_kernel(const float *__restrict
                                                          int Ci, int h, int w, int normalize, int B, float *__restrict__ ws) {
     __shared__ float red[4];
     const int b = blockIdx.y, hw = h * w;
-    const float dn = normalize ? ws[b] + 1e-7f : 1.f;
+    const float dn = normalize ? sample_mean(ws, B, b, hw, red) + 1e-7f : 1.f;
     const float *d = disp + (size_t)b * hw, *im = img + (size_t)b * Ci * hw;
     float sx = 0.f, sy = 0.f;
     for (int p = blockIdx.x * 256 + threadIdx.x; p < hw; p += SM_BLK * 256) {
@@ -135,7 +143,7 @@ __global__ __launch_bounds__(256) void smooth_bwd_kernel(const float *__restrict
                                                          int B, float *__restrict__ d_disp, float *__restrict__ ws) {
     __shared__ float red[4];
     const int b = blockIdx.y, hw = h * w;
-    const float dn = normalize ? ws[b] + 1e-7f : 1.f;
+    const float dn = normalize ? sample_mean(ws, B, b, hw, red) + 1e-7f : 1.f;
     const float cx = gloss[0] / ((float)B * h * (w - 1)), cy = gloss[0] / ((float)B * (h - 1) * w);
     const float *d = disp + (size_t)b * hw, *im = img + (size_t)b * Ci * hw;
     float dot = 0.f;
@@ -156,8 +164,9 @@ __global__ __launch_bounds__(256) void smooth_bwd_kernel(const float *__restrict
 
 // pass 2: nd = d / (mean + 1e-7)  =>  d_d[q] = gn[q]/dn - dot/(dn^2 hw)
 __global__ __launch_bounds__(256) void smooth_bwd_finish_kernel(int hw, int B, float *__restrict__ d_disp, const float *__restrict__ ws) {
+    __shared__ float red[4];
     const int b = blockIdx.y;
-    const float dn = ws[b] + 1e-7f;
+    const float dn = sample_mean(ws, B, b, hw, red) + 1e-7f;
     float dot = 0.f;
     for (int k = 0; k < SM_BLK; ++k) dot += ws[B + (size_t)B * SM_BLK * 2 + (size_t)b * SM_BLK + k];
     const float corr = dot / (dn * dn) / (float)hw;
@@ -196,7 +205,7 @@ extern "C" int md_masked_min_bwd(const float *gloss, const float *reproj, const 
 
 extern "C" size_t md_smooth_ws_bytes(int B, int h, int w) {
     (void)h; (void)w;
-    return sizeof(float) * ((size_t)B + (size_t)B * SM_BLK * 3);
+    return sizeof(float) * ((size_t)B + (size_t)B * SM_BLK * 4);
 }
 
 extern "C" int md_smooth_fwd(const float *disp, const float *img, int B, int Ci, int h, int w, int normalize, float *loss,
@@ -204,7 +213,7 @@ extern "C" int md_smooth_fwd(const float *disp, const float *img, int B, int Ci,
     MD_REQUIRE(disp && img && loss && ws, "md_smooth_fwd: null tensor");
     MD_REQUIRE(B > 0 && B <= 65535 && Ci > 0 && h > 1 && w > 1, "md_smooth_fwd: bad dims");
     if (normalize) {
-        hipLaunchKernelGGL(smooth_mean_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, disp, h * w, (float *)ws);
+        hipLaunchKernelGGL(smooth_mean_kernel, dim3(SM_BLK, B), dim3(256), 0, (hipStream_t)stream, disp, h * w, B, (float *)ws);
         MD_CHECK_LAUNCH("md_smooth_fwd(mean)");
     }
     hipLaunchKernelGGL(smooth_fwd_kernel, dim3(SM_BLK, B), dim3(256), 0, (hipStream_t)stream, disp, img, Ci, h, w, normalize,
@@ -220,7 +229,7 @@ extern "C" int md_smooth_bwd(const float *gloss, const float *disp, const float 
     MD_REQUIRE(gloss && disp && img && d_disp && ws, "md_smooth_bwd: null tensor");
     MD_REQUIRE(B > 0 && B <= 65535 && Ci > 0 && h > 1 && w > 1, "md_smooth_bwd: bad dims");
     if (normalize) {  // recompute the means: the workspace need not survive between forward and backward
-        hipLaunchKernelGGL(smooth_mean_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, disp, h * w, (float *)ws);
+        hipLaunchKernelGGL(smooth_mean_kernel, dim3(SM_BLK, B), dim3(256), 0, (hipStream_t)stream, disp, h * w, B, (float *)ws);
         MD_CHECK_LAUNCH("md_smooth_bwd(mean)");
     }
     hipLaunchKernelGGL(smooth_bwd_kernel, dim3(SM_BLK, B), dim3(256), 0, (hipStream_t)stream, gloss, disp, img, Ci, h, w,

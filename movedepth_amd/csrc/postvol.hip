@@ -97,6 +97,123 @@ __global__ __launch_bounds__(256) void sel_bwd_kernel(const float *__restrict__ 
     }
 }
 
+// ---- D split over four threads per pixel (D <= 128) --------------------------------------------------------------
+// One thread per pixel walks D bins three to four times with dependent loads and, at 48x160, gives 180 workgroups for
+// 256 CUs: 74 / 129 us forward / backward for 18-53 MB of traffic.  Here a workgroup is 64 pixels x 4 contiguous
+// quarters of D (wave = quarter, so each load is 64 consecutive pixels of one bin); a thread keeps its <= 32 logits
+// in registers for all passes (one global read) and the quarters meet through LDS.  Ties of the maximum resolve to the
+// first bin as before: quarters are scanned in order with a strict comparison.
+constexpr int SEL_NB = 32;  // bins per thread, upper bound
+
+struct SelShared {
+    float f[4][4][64];  // [slot][quarter][pixel]
+    int am[4][64];
+};
+
+__device__ __forceinline__ int sel_mult(int d, int D, int lo, int hi) {  // multiplicity of bin d among the clamped window
+    int m = (d >= lo && d <= hi) ? 1 : 0;
+    if (d == 0 && lo < 0) m += -lo;
+    if (d == D - 1 && hi > D - 1) m += hi - (D - 1);
+    return m;
+}
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void sel4_kernel(const float *__restrict__ g_depth, const float *__restrict__ g_entropy,
+                                                   const float *__restrict__ logits, int D, int hw, int radius,
+                                                   const float *__restrict__ min_inv, const float *__restrict__ max_inv,
+                                                   float *__restrict__ prob, float *__restrict__ entropy,
+                                                   float *__restrict__ depth, float *__restrict__ d_logits) {
+    __shared__ SelShared sh;
+    const int b = blockIdx.y, pl = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int p = blockIdx.x * 64 + pl;
+    const bool valid = p < hw;
+    const size_t shw = (size_t)hw;
+    const int nb = (D + 3) / 4, dbeg = q * nb;
+    const float *lp = logits + (size_t)b * D * shw + (valid ? p : 0);
+    float v[SEL_NB];
+    float mx = -INFINITY;
+    int am = 0;
+#pragma unroll
+    for (int i = 0; i < SEL_NB; ++i) {
+        const int d = dbeg + i;
+        v[i] = (i < nb && d < D) ? lp[d * shw] : -INFINITY;
+        if (v[i] > mx) { mx = v[i]; am = d; }
+    }
+    sh.f[0][q][pl] = mx;
+    sh.am[q][pl] = am;
+    __syncthreads();
+    mx = sh.f[0][0][pl]; am = sh.am[0][pl];
+#pragma unroll
+    for (int k = 1; k < 4; ++k)
+        if (sh.f[0][k][pl] > mx) { mx = sh.f[0][k][pl]; am = sh.am[k][pl]; }
+    float den = 0.f;
+#pragma unroll
+    for (int i = 0; i < SEL_NB; ++i) {
+        v[i] = (i < nb && dbeg + i < D) ? expf(v[i] - mx) : 0.f;
+        den += v[i];
+    }
+    sh.f[1][q][pl] = den;
+    __syncthreads();
+    den = (sh.f[1][0][pl] + sh.f[1][1][pl]) + (sh.f[1][2][pl] + sh.f[1][3][pl]);
+    const int lo = am - radius, hi = am + radius;
+    float num = 0.f, wden = 0.f, ent = 0.f;
+#pragma unroll
+    for (int i = 0; i < SEL_NB; ++i) {
+        const int d = dbeg + i;
+        if (i < nb && d < D) {
+            v[i] = v[i] / den;  // probability
+            const int m = sel_mult(d, D, lo, hi);
+            num += (float)(m * d) * v[i];
+            wden += (float)m * v[i];
+            if (!BWD) {
+                if (prob && valid) prob[(size_t)b * D * shw + d * shw + p] = v[i];
+                ent += -v[i] * logf(fminf(fmaxf(v[i], 1e-9f), 1.f));
+            }
+        }
+    }
+    sh.f[2][q][pl] = num; sh.f[3][q][pl] = wden;
+    if (!BWD) sh.f[0][q][pl] = ent;  // slot 0 is free again: every thread passed the second barrier after reading it
+    __syncthreads();
+    num = (sh.f[2][0][pl] + sh.f[2][1][pl]) + (sh.f[2][2][pl] + sh.f[2][3][pl]);
+    wden = 1e-6f + ((sh.f[3][0][pl] + sh.f[3][1][pl]) + (sh.f[3][2][pl] + sh.f[3][3][pl]));
+    const float r = num / wden;
+    const float a = valid ? min_inv[(size_t)b * shw + p] : 1.f, bb = valid ? max_inv[(size_t)b * shw + p] : 1.f;
+    const float dep = 1.f / (a + (r / (float)(D - 1)) * (bb - a));
+    if (!BWD) {
+        if (q == 0 && valid) {
+            depth[(size_t)b * shw + p] = dep;
+            if (entropy) entropy[(size_t)b * shw + p] = (sh.f[0][0][pl] + sh.f[0][1][pl]) + (sh.f[0][2][pl] + sh.f[0][3][pl]);
+        }
+        return;
+    }
+    const float gd = (g_depth && valid) ? g_depth[(size_t)b * shw + p] : 0.f;
+    const float g_r = -gd * dep * dep * (bb - a) / (float)(D - 1);
+    const float ge = (g_entropy && valid) ? g_entropy[(size_t)b * shw + p] : 0.f;
+    float gp[SEL_NB];
+    float dot = 0.f;
+#pragma unroll
+    for (int i = 0; i < SEL_NB; ++i) {
+        const int d = dbeg + i;
+        gp[i] = 0.f;
+        if (i < nb && d < D) {
+            const float pv = v[i];
+            if (ge != 0.f) gp[i] += ge * ((pv < 1e-9f) ? -logf(1e-9f) : (pv > 1.f ? 0.f : -logf(pv) - 1.f));
+            const int m = sel_mult(d, D, lo, hi);
+            if (m) gp[i] += g_r * (float)m * ((float)d - r) / wden;
+            dot += gp[i] * pv;
+        }
+    }
+    sh.f[0][q][pl] = dot;
+    __syncthreads();
+    dot = (sh.f[0][0][pl] + sh.f[0][1][pl]) + (sh.f[0][2][pl] + sh.f[0][3][pl]);
+    float *dl = d_logits + (size_t)b * D * shw + p;
+#pragma unroll
+    for (int i = 0; i < SEL_NB; ++i) {
+        const int d = dbeg + i;
+        if (i < nb && d < D && valid) dl[d * shw] = v[i] * (gp[i] - dot);
+    }
+}
+
 }  // namespace
 
 extern "C" int md_softmax_entropy_localmax_fwd(const float *logits, int B, int D, int h, int w, int radius,
@@ -104,8 +221,12 @@ extern "C" int md_softmax_entropy_localmax_fwd(const float *logits, int B, int D
                                                float *depth, md_stream_t stream) {
     MD_REQUIRE(logits && min_inv && max_inv && depth, "md_softmax_entropy_localmax_fwd: null tensor");
     MD_REQUIRE(B > 0 && B <= 65535 && D > 1 && h > 0 && w > 0 && radius >= 0, "md_softmax_entropy_localmax_fwd: bad dims");
-    hipLaunchKernelGGL(sel_fwd_kernel, dim3(md_cdiv(h * w, 256), B), dim3(256), 0, (hipStream_t)stream, logits, D, h * w,
-                       radius, min_inv, max_inv, prob, entropy, depth);
+    if (D <= 4 * SEL_NB)
+        hipLaunchKernelGGL(sel4_kernel<false>, dim3(md_cdiv(h * w, 64), B), dim3(256), 0, (hipStream_t)stream, nullptr, nullptr,
+                           logits, D, h * w, radius, min_inv, max_inv, prob, entropy, depth, nullptr);
+    else
+        hipLaunchKernelGGL(sel_fwd_kernel, dim3(md_cdiv(h * w, 256), B), dim3(256), 0, (hipStream_t)stream, logits, D, h * w,
+                           radius, min_inv, max_inv, prob, entropy, depth);
     MD_CHECK_LAUNCH("md_softmax_entropy_localmax_fwd");
     return MD_OK;
 }
@@ -115,8 +236,12 @@ extern "C" int md_softmax_entropy_localmax_bwd(const float *g_depth, const float
                                                const float *max_inv, float *d_logits, md_stream_t stream) {
     MD_REQUIRE(logits && min_inv && max_inv && d_logits, "md_softmax_entropy_localmax_bwd: null tensor");
     MD_REQUIRE(B > 0 && B <= 65535 && D > 1 && h > 0 && w > 0 && radius >= 0, "md_softmax_entropy_localmax_bwd: bad dims");
-    hipLaunchKernelGGL(sel_bwd_kernel, dim3(md_cdiv(h * w, 256), B), dim3(256), 0, (hipStream_t)stream, g_depth, g_entropy,
-                       logits, D, h * w, radius, min_inv, max_inv, d_logits);
+    if (D <= 4 * SEL_NB)
+        hipLaunchKernelGGL(sel4_kernel<true>, dim3(md_cdiv(h * w, 64), B), dim3(256), 0, (hipStream_t)stream, g_depth, g_entropy,
+                           logits, D, h * w, radius, min_inv, max_inv, nullptr, nullptr, nullptr, d_logits);
+    else
+        hipLaunchKernelGGL(sel_bwd_kernel, dim3(md_cdiv(h * w, 256), B), dim3(256), 0, (hipStream_t)stream, g_depth, g_entropy,
+                           logits, D, h * w, radius, min_inv, max_inv, d_logits);
     MD_CHECK_LAUNCH("md_softmax_entropy_localmax_bwd");
     return MD_OK;
 }

@@ -325,6 +325,34 @@ def test_postvol_golden(ops):
     assert_close(host(d2), g["depth_r2"], rtol=1e-5)
 
 
+@pytest.mark.parametrize("shape,radius", [((2, 13, 7, 9), 1), ((1, 96, 48, 160), 1), ((2, 5, 3, 70), 2), ((1, 130, 6, 11), 1),
+                                          ((1, 128, 4, 65), 3)])
+def test_postvol_vs_oracle_and_torch(ops, oracle_lib, shape, radius):
+    """D not a multiple of 4, ragged pixel counts, the BASELINE size, and D > 128 (one-thread-per-pixel fallback):
+    forward against the oracle; backward against torch autograd of the reference's own formulation
+    (layers.localmax / layers.entropy are line-by-line torch restatements)."""
+    from movedepth_amd import layers
+    rng = np.random.default_rng(41)
+    B, D, h, w = shape
+    logits = (rng.standard_normal(shape) * 2).astype(np.float32)
+    a = (0.02 + 0.05 * rng.random((B, h, w))).astype(np.float32)
+    b = (a + 0.1 + 0.2 * rng.random((B, h, w))).astype(np.float32)
+    prob = oracle_lib.softmax_d(logits)
+    lg = dev(logits, True)
+    depth, ent, pr = ops.softmax_entropy_localmax(lg, dev(a), dev(b), radius, want_prob=True)
+    assert_close(host(pr), prob, rtol=1e-5, what="prob")
+    assert_close(host(ent), oracle_lib.entropy(prob), rtol=1e-5, what="entropy")
+    assert_close(host(depth), oracle_lib.localmax(prob, radius, a, b), rtol=1e-5, what="depth")
+    gd, ge = dev(rng.standard_normal((B, h, w)).astype(np.float32)), dev(rng.standard_normal((B, 1, h, w)).astype(np.float32))
+    ((depth * gd).sum() + (ent * ge).sum()).backward()
+    lt = dev(logits, True)
+    pt = torch.softmax(lt, 1)
+    dt = layers.localmax(pt, radius, D, dev(a), dev(b))
+    et = layers.entropy(pt, dim=1, keepdim=True)
+    ((dt * gd).sum() + (et * ge).sum()).backward()
+    assert_close(host(lg.grad), host(lt.grad), rtol=2e-4, what="d_logits")
+
+
 def test_convex_upsample_golden(ops):
     g = load_golden("postvol")
     depth, mask = dev(g["up_depth"], True), dev(g["up_mask"], True)
