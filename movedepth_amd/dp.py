@@ -88,4 +88,6 @@ def broadcast_parameters(modules, src=0, process_group=None):
         return
     for m in modules:
         for t in list(m.parameters()) + list(m.buffers()):
+            if t.device.type == "cpu" and dist.get_backend(process_group) == "nccl":
+                continue  # host-resident BatchNorm counters (--bn_counter_on_host): identical on every rank at start
             dist.broadcast(t.data, src=src, group=process_group)

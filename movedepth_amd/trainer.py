@@ -98,10 +98,17 @@ class Trainer:
             if opt.ddp and opt.sync_bn and not share_gpu:
                 m = torch.nn.SyncBatchNorm.convert_sync_batchnorm(m)
             self.models[k] = m.to(self.device)
-            if opt.nets2d_channels_last and k != "reg3d":
+            if opt.nets2d_channels_last and k != "reg3d" and k not in opt.nets2d_channels_last_skip.split(","):
                 # 2-D networks in channels_last: same results (outputs equal to 1e-7, tests/test_trainer_parity.py), the
                 # library's NHWC kernels without the NCHW<->NHWC transposes around them; -2.1 ms per step at config 2
                 self.models[k] = self.models[k].to(memory_format=torch.channels_last)
+        if opt.bn_counter_on_host:
+            # BatchNorm's num_batches_tracked += 1 is a GPU kernel per BatchNorm call (115 per step, ~0.5 ms) for a counter
+            # nothing on the device reads (momentum is fixed): keep the counters in host memory.  Same state_dict.
+            for m in self.models.values():
+                for mod in m.modules():
+                    if isinstance(mod, torch.nn.modules.batchnorm._BatchNorm) and mod.num_batches_tracked is not None:
+                        mod.num_batches_tracked = mod.num_batches_tracked.cpu()
         for k in main:
             self.parameters_to_train += list(self.models[k].parameters())
         for k in mvs:
