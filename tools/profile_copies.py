@@ -21,13 +21,19 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_sh
     t.train_step(dict(inputs))
     torch.cuda.synchronize()
 agg = collections.defaultdict(lambda: [0, 0.0])
+only = os.environ.get("OPS")  # comma-separated aten op names; default: every op, by self GPU time
 for e in prof.key_averages(group_by_input_shape=True):
-    if e.key in ("aten::copy_", "aten::contiguous", "aten::clone", "aten::_to_copy", "aten::fill_", "aten::zero_", "aten::add_", "aten::add",
-                 "aten::cat", "aten::mul", "aten::threshold_backward", "aten::clamp_min_", "aten::relu_", "aten::elu", "aten::elu_backward"):
-        k = (e.key, str(e.input_shapes)[:90])
-        agg[k][0] += e.count
-        agg[k][1] += e.device_time_total if hasattr(e, "device_time_total") else e.cuda_time_total
-rows = sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]
-print("%-26s %-92s %6s %10s" % ("op", "input shapes", "calls", "gpu us"))
-for (k, shp), (c, us) in rows:
-    print("%-26s %-92s %6d %10.0f" % (k, shp, c, us))
+    if only and e.key not in only.split(","):
+        continue
+    us = e.self_device_time_total if hasattr(e, "self_device_time_total") else e.self_cuda_time_total
+    if us <= 0:
+        continue
+    k = (e.key, str(e.input_shapes)[:100])
+    agg[k][0] += e.count
+    agg[k][1] += us
+rows = sorted(agg.items(), key=lambda kv: -kv[1][1])
+tot = sum(v[1] for _, v in rows)
+print("total self GPU time of one step: %.2f ms over %d (op, shape) groups" % (tot / 1e3, len(rows)))
+print("%-44s %-102s %6s %10s" % ("op", "input shapes", "calls", "gpu us"))
+for (k, shp), (c, us) in rows[:int(os.environ.get("TOP", "60"))]:
+    print("%-44s %-102s %6d %10.0f" % (k[:44], shp, c, us))
