@@ -188,6 +188,14 @@ int md_conv3d_c16_bwd_weight(const float *x, int x_planar, const float *gy, floa
                              long long dw_stride_ci, long long dw_stride_k, void *ws, size_t ws_bytes, int B, int Ci, int Co,
                              int D, int H, int W, md_stream_t stream);
 
+/* ---- pose parameters -> 4x4 -------------------------------------------------------------------
+ * transformation_from_parameters (layers.py:412-429; rot_from_axisangle :479-518, get_translation_matrix :464-477):
+ * axisangle, translation [B,3] -> T [B,4,4]; invert != 0: R^T . T(-t), else T(t) . R.  The reference's
+ * axis = v / (|v| + 1e-7) is kept.  Backward: gT [B,4,4] -> d_axisangle, d_translation [B,3] (d|v|/dv = 0 at v = 0). */
+int md_pose_matrix_fwd(const float *axisangle, const float *translation, int B, int invert, float *T, md_stream_t stream);
+int md_pose_matrix_bwd(const float *gT, const float *axisangle, const float *translation, int B, int invert,
+                       float *d_axisangle, float *d_translation, md_stream_t stream);
+
 /* ---- standalone geometry, for call compatibility (the hot kernels fuse these; forward only) -------
  * BackprojectDepth.forward (layers.py:581-586): depth [Bs,h*w], invK [nk,4,4] (nk = 1 or Bs) -> cam_points [Bs,4,h*w].
  * Project3D.forward (layers.py:601-621): points [Bs,4,h*w], K, T [nk,4,4] -> pix [Bs,h,w,2] in [-1,1]. */

@@ -52,6 +52,8 @@ SIGNATURES = {
     "md_conv3d_c16_bwd_data": (_i, [_vp, _vp, _ll, _ll, _ll, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "md_conv3d_c16_bwd_weight_ws_bytes": (_sz, [_i, _i, _i, _i]),
     "md_conv3d_c16_bwd_weight": (_i, [_vp, _i, _vp, _vp, _ll, _ll, _ll, _vp, _sz, _i, _i, _i, _i, _i, _i, _vp]),
+    "md_pose_matrix_fwd": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
+    "md_pose_matrix_bwd": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     "md_backproject": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "md_project3d": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp]),
 }

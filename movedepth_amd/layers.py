@@ -7,8 +7,8 @@ What differs by design, not by accident:
     HIP kernels of their own when called without autograd (as generate_costvol does upstream, layers.py:784);
   * generate_costvol returns the reference's (B,D,C,h,w) volume (G == C in the fused kernel); the trainer uses
     generate_costvol_grouped, which never materialises the C axis (SURVEY hard part 2).
-Glue that is not on the measured path (Rodrigues 4x4 from 6 numbers) stays as torch ops on the GPU; it is the
-autograd-visible tail of the pose network.
+The pose tail (Rodrigues 4x4 from 6 numbers) is one HIP kernel each way on the GPU; its torch-op form is kept
+for CPU host use.
 """
 import numpy as np
 import torch
@@ -54,7 +54,11 @@ def get_translation_matrix(translation_vector):
 
 
 def transformation_from_parameters(axisangle, translation, invert=False):
-    """(axisangle, translation) -> 4x4; invert => R^T @ T(-t) else T(t) @ R.  reference layers.py:412-429"""
+    """(axisangle, translation) -> 4x4; invert => R^T @ T(-t) else T(t) @ R.  reference layers.py:412-429.
+    On the GPU one kernel forward, one backward (ops.pose_matrix); the torch-op form below is the CPU host path the
+    tests use and costs ~75 launches each way."""
+    if axisangle.is_cuda:
+        return ops.pose_matrix(axisangle, translation, invert)
     R = rot_from_axisangle(axisangle)
     t = translation.clone()
     if invert:

@@ -574,6 +574,36 @@ def conv3d_16(x, weight, lib_fwd_dgrad=False):
     return _Conv3d16.apply(x.float(), weight.float(), lib_fwd_dgrad)
 
 
+# --------------------------------------------------------------------------- pose parameters -> 4x4
+class _PoseMatrix(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, axisangle, translation, invert):
+        aa, tr = _prep(axisangle, "axisangle").reshape(-1, 3), _prep(translation, "translation").reshape(-1, 3)
+        if aa.shape != tr.shape:
+            raise _lib.MovedepthHipError("pose_matrix: axisangle %s and translation %s differ" % (tuple(axisangle.shape),
+                                                                                               tuple(translation.shape)))
+        B = aa.shape[0]
+        T = torch.empty(B, 4, 4, device=aa.device, dtype=torch.float32)
+        _lib.call("md_pose_matrix_fwd", _p(aa), _p(tr), B, int(bool(invert)), _p(T), _stream())
+        ctx.save_for_backward(aa, tr)
+        ctx.invert = int(bool(invert))
+        ctx.shapes = (axisangle.shape, translation.shape)
+        return T
+
+    @staticmethod
+    def backward(ctx, gT):
+        aa, tr = ctx.saved_tensors
+        gT = gT.contiguous().float()
+        d_aa, d_tr = torch.empty_like(aa), torch.empty_like(tr)
+        _lib.call("md_pose_matrix_bwd", _p(gT), _p(aa), _p(tr), aa.shape[0], ctx.invert, _p(d_aa), _p(d_tr), _stream())
+        return d_aa.reshape(ctx.shapes[0]), d_tr.reshape(ctx.shapes[1]), None
+
+
+def pose_matrix(axisangle, translation, invert=False):
+    """transformation_from_parameters (reference layers.py:412-429): (B,1,3) or (B,3) each -> (B,4,4), differentiable."""
+    return _PoseMatrix.apply(axisangle, translation, invert)
+
+
 def backproject(depth, inv_K, batch_size, height, width):
     """BackprojectDepth.forward (reference layers.py:581-586), forward only -> (Bs,4,h*w)."""
     with torch.no_grad():

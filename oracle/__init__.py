@@ -84,6 +84,14 @@ def transformation_from_parameters(axisangle, translation, invert=False):
     return out
 
 
+def transformation_from_parameters_bwd(gT, axisangle, translation, invert=False):
+    """adjoint of transformation_from_parameters: gT [B,4,4] -> (d_axisangle [B,3], d_translation [B,3])"""
+    aa, tr, g = _c(axisangle).reshape(-1, 3), _c(translation).reshape(-1, 3), _c(gT).reshape(-1, 16)
+    d_aa, d_tr = np.empty_like(aa), np.empty_like(tr)
+    lib().mdo_transformation_from_parameters_bwd(_p(g), _p(aa), _p(tr), _i(aa.shape[0]), _i(int(invert)), _p(d_aa), _p(d_tr))
+    return d_aa, d_tr
+
+
 _TYPES = {"inverse": 0, "linear": 1, "log": 2}
 
 

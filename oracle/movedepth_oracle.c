@@ -1033,3 +1033,44 @@ void mdo_conv3d(const float *x, const float *wt, const float *gy, int B, int Ci,
         }
     }
 }
+
+/* Adjoint of mdo_transformation_from_parameters (what torch autograd computes for layers.py:412-429): gT [B,16] ->
+ * d_axisangle, d_translation [B,3].  fp64 arithmetic.  d|v|/dv is taken as 0 at v = 0 (torch's norm backward). */
+void mdo_transformation_from_parameters_bwd(const float *gT, const float *aa, const float *tr, int B, int invert,
+                                            float *d_aa, float *d_tr) {
+    for (int b = 0; b < B; ++b) {
+        double v[3] = {aa[b * 3], aa[b * 3 + 1], aa[b * 3 + 2]}, t[3] = {tr[b * 3], tr[b * 3 + 1], tr[b * 3 + 2]};
+        const float *g = gT + b * 16;
+        double angle = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]), s = angle + 1e-7;
+        double x = v[0] / s, y = v[1] / s, z = v[2] / s, ca = cos(angle), sa = sin(angle), C = 1.0 - ca;
+        double R[9] = {x * x * C + ca, x * y * C - z * sa, z * x * C + y * sa, x * y * C + z * sa, y * y * C + ca,
+                       y * z * C - x * sa, z * x * C - y * sa, y * z * C + x * sa, z * z * C + ca};
+        double G[9], gt[3] = {0, 0, 0};
+        if (invert) { /* M[i][j] = R[j][i], M[i][3] = -sum_j R[j][i] t_j */
+            for (int i = 0; i < 3; ++i)
+                for (int j = 0; j < 3; ++j) {
+                    G[j * 3 + i] = (double)g[i * 4 + j] - (double)g[i * 4 + 3] * t[j];
+                    gt[j] -= (double)g[i * 4 + 3] * R[j * 3 + i];
+                }
+        } else {
+            for (int i = 0; i < 3; ++i) {
+                for (int j = 0; j < 3; ++j) G[i * 3 + j] = g[i * 4 + j];
+                gt[i] = g[i * 4 + 3];
+            }
+        }
+        double s01 = G[1] + G[3], s02 = G[2] + G[6], s12 = G[5] + G[7];
+        double gx = G[0] * 2 * x * C + s01 * y * C + s02 * z * C + (G[7] - G[5]) * sa;
+        double gy = G[4] * 2 * y * C + s01 * x * C + s12 * z * C + (G[2] - G[6]) * sa;
+        double gz = G[8] * 2 * z * C + s02 * x * C + s12 * y * C + (G[3] - G[1]) * sa;
+        double gC = G[0] * x * x + G[4] * y * y + G[8] * z * z + s01 * x * y + s02 * z * x + s12 * y * z;
+        double gca = G[0] + G[4] + G[8] - gC;
+        double gsa = (G[3] - G[1]) * z + (G[2] - G[6]) * y + (G[7] - G[5]) * x;
+        double gth = -gca * sa + gsa * ca;
+        double dotgv = gx * v[0] + gy * v[1] + gz * v[2];
+        double k = angle > 0 ? (gth - dotgv / (s * s)) / angle : 0.0;
+        d_aa[b * 3] = (float)(gx / s + k * v[0]);
+        d_aa[b * 3 + 1] = (float)(gy / s + k * v[1]);
+        d_aa[b * 3 + 2] = (float)(gz / s + k * v[2]);
+        for (int i = 0; i < 3; ++i) d_tr[b * 3 + i] = (float)gt[i];
+    }
+}

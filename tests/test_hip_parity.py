@@ -680,3 +680,45 @@ def test_reg3d_conv0_paths_agree(ops, vol_layout):
             assert_close(a, b, rtol=1e-4 if flips == 0 else 5e-3, what="%s (%d ReLU flips)" % (what, flips))
 
 
+
+
+# ------------------------------------------------------------------ pose parameters -> 4x4
+@pytest.mark.parametrize("invert", [False, True])
+def test_pose_matrix_golden(ops, invert):
+    g = load_golden("pose_grad")
+    k = "_inv" if invert else ""
+    aa, tr = dev(g["axisangle"], True), dev(g["translation"], True)
+    T = ops.pose_matrix(aa, tr, invert)
+    assert_close(host(T), g["T" + k], rtol=1e-6)
+    (T * dev(g["grad_T" + k])).sum().backward()
+    assert aa.grad.shape == aa.shape and tr.grad.shape == tr.shape
+    # sample 5 (|v| = 5.9e-5) is ill-conditioned in fp32 for the reference as well (see test_oracle_golden.py): compare the
+    # well-conditioned samples with the reference, the tiny-angle one with the fp64 oracle at a looser bound
+    assert_close(host(aa.grad)[:5], g["d_axisangle" + k][:5], rtol=1e-5, what="d_axisangle")
+    import oracle
+    oracle.build()
+    da64, _ = oracle.transformation_from_parameters_bwd(g["grad_T" + k], g["axisangle"], g["translation"], invert)
+    assert_close(host(aa.grad).reshape(-1, 3)[5:], da64[5:], rtol=1e-3, what="d_axisangle (tiny angle) vs fp64 oracle")
+    assert_close(host(tr.grad), g["d_translation" + k], rtol=1e-5, what="d_translation")
+
+
+def test_pose_matrix_matches_torch_form_and_layers_dispatch(ops):
+    """layers.transformation_from_parameters uses the kernel on the GPU and torch ops on the CPU: same values/gradients;
+    zero rotation gives the identity rotation and a finite (zero) angle gradient."""
+    from movedepth_amd import layers
+    torch.manual_seed(9)
+    aa = torch.randn(16, 1, 3) * 0.2
+    tr = torch.randn(16, 1, 3)
+    aa[0] = 0.0
+    for inv in (False, True):
+        a_c, t_c = aa.clone().requires_grad_(True), tr.clone().requires_grad_(True)
+        a_g, t_g = aa.cuda().requires_grad_(True), tr.cuda().requires_grad_(True)
+        Tc, Tg = layers.transformation_from_parameters(a_c, t_c, inv), layers.transformation_from_parameters(a_g, t_g, inv)
+        W = torch.randn(16, 4, 4)
+        (Tc * W).sum().backward()
+        (Tg * W.cuda()).sum().backward()
+        assert_close(host(Tg), Tc.detach().numpy(), rtol=1e-6)
+        assert torch.isfinite(a_g.grad).all()
+        assert_close(host(a_g.grad)[1:], a_c.grad.numpy()[1:], rtol=1e-5, what="d_axisangle")  # [0]: torch gives nan/0 at v = 0
+        assert_close(host(t_g.grad), t_c.grad.numpy(), rtol=1e-5, what="d_translation")
+    np.testing.assert_allclose(host(Tg)[0, :3, :3] if inv else host(Tg)[0, :3, :3], np.eye(3), atol=1e-7)

@@ -398,6 +398,25 @@ def gen_prob_conv(networks):
                                       d_weight=net.prob.weight.grad))
 
 
+def gen_pose_grad(L):
+    """transformation_from_parameters through the reference with gradients (both invert modes), incl. a large angle and
+    a nearly-zero rotation."""
+    g = torch.Generator().manual_seed(831)
+    B = 6
+    out = {}
+    aa = torch.randn(B, 1, 3, generator=g) * torch.tensor([0.01, 0.05, 0.3, 1.0, 2.5, 1e-4]).view(B, 1, 1)
+    tr = torch.randn(B, 1, 3, generator=g)
+    out["axisangle"], out["translation"] = aa, tr
+    for inv in (False, True):
+        a, t = aa.clone().requires_grad_(True), tr.clone().requires_grad_(True)
+        T = L.transformation_from_parameters(a, t, invert=inv)
+        W = torch.randn(T.shape, generator=g)
+        (T * W).sum().backward()
+        k = "_inv" if inv else ""
+        out["T" + k], out["grad_T" + k], out["d_axisangle" + k], out["d_translation" + k] = T, W, a.grad, t.grad
+    save("pose_grad", out)
+
+
 def gen_conv0(networks):
     """reg3d's first convolution through the reference's own module (conv0.conv, networks/resnet_encoder.py:231,
     applied :258 on the permuted volume): output and both gradients.  Ragged size."""
@@ -417,6 +436,7 @@ def main():
     L, Trainer, networks = load_reference(with_trainer=True)
     gen_prob_conv(networks)
     gen_conv0(networks)
+    gen_pose_grad(L)
     gen_geometry(L)
     gen_schedule(L)
     gen_costvol(L)
