@@ -188,6 +188,25 @@ int md_conv3d_c16_bwd_weight(const float *x, int x_planar, const float *gy, floa
                              long long dw_stride_ci, long long dw_stride_k, void *ws, size_t ws_bytes, int B, int Ci, int Co,
                              int D, int H, int W, md_stream_t stream);
 
+/* ---- training-mode BatchNorm + ReLU (+ residual) of the regulariser's two full-resolution layers -------------
+ * conv0's BatchNorm3d + ReLU (networks/resnet_encoder.py:231 through ConvBnReLU3D) and conv11's BatchNorm3d + ReLU
+ * followed by `x = conv0 + self.conv11(x)` (:249-252, :264).  x, y, res, dy, dx: channels-last volumes flattened to
+ * [nvox,16].  Two-phase so that a data-parallel caller can all-reduce the 32 sums in between (SyncBatchNorm):
+ *   md_bn_relu_stats      -> sums[0:16] = sum x, sums[16:32] = sum x^2          (caller: mean, biased var, invstd)
+ *   md_bn_relu_apply      y = max(0, (x - mean) * invstd * gamma + beta) [+ res]   (res may be NULL; y may alias x)
+ *   md_bn_relu_bwd_reduce -> sums[0:16] = sum dz (= dbeta), sums[16:32] = sum dz * xhat (= dgamma), dz = dy * [z > 0]
+ *   md_bn_relu_bwd_dx     dx = gamma * invstd * (dz - sums[0]/n_total - xhat * sums[1]/n_total)
+ * ws: md_bn_relu_ws_bytes() bytes.  Reductions are two-stage in a fixed order (fp64 final sum). */
+size_t md_bn_relu_ws_bytes(void);
+int md_bn_relu_stats(const float *x, long long nvox, int C, float *sums, void *ws, md_stream_t stream);
+int md_bn_relu_apply(const float *x, const float *mean, const float *invstd, const float *gamma, const float *beta,
+                     const float *res, long long nvox, int C, float *y, md_stream_t stream);
+int md_bn_relu_bwd_reduce(const float *dy, const float *x, const float *mean, const float *invstd, const float *gamma,
+                          const float *beta, long long nvox, int C, float *sums, void *ws, md_stream_t stream);
+int md_bn_relu_bwd_dx(const float *dy, const float *x, const float *mean, const float *invstd, const float *gamma,
+                      const float *beta, const float *sums, long long n_total, long long nvox, int C, float *dx,
+                      md_stream_t stream);
+
 /* ---- pose parameters -> 4x4 -------------------------------------------------------------------
  * transformation_from_parameters (layers.py:412-429; rot_from_axisangle :479-518, get_translation_matrix :464-477):
  * axisangle, translation [B,3] -> T [B,4,4]; invert != 0: R^T . T(-t), else T(t) . R.  The reference's

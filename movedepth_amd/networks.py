@@ -304,7 +304,39 @@ class ConvBnReLU3D(nn.Module):
         self.bn = nn.BatchNorm3d(cout)
 
     def forward(self, x):
-        return F.relu(self.bn(self.conv(x)), inplace=True)
+        y = self.bn(self.conv(x))
+        return y if isinstance(self.bn, FusedBNReLU3d) else F.relu(y, inplace=True)   # the fused module includes the ReLU
+
+
+class FusedBNReLU3d(nn.Module):
+    """BatchNorm3d followed by ReLU (and optionally a residual add) with BatchNorm3d's parameter / buffer names, so that
+    checkpoints are interchangeable.  On the GPU, in training mode, on a channels_last_3d 16-channel tensor this is
+    ops.bn_relu_3d (3 + 5 passes over the tensor instead of 13); anywhere else it is the torch ops.  Not a _BatchNorm
+    subclass on purpose: SyncBatchNorm conversion skips it, `sync_group` makes it reduce its statistics itself."""
+
+    def __init__(self, num_features, eps=1e-5, momentum=0.1):
+        super().__init__()
+        self.num_features, self.eps, self.momentum = num_features, eps, momentum
+        self.weight = nn.Parameter(torch.ones(num_features))
+        self.bias = nn.Parameter(torch.zeros(num_features))
+        self.register_buffer("running_mean", torch.zeros(num_features))
+        self.register_buffer("running_var", torch.ones(num_features))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+        self.fused = True
+        self.sync_group = None  # torch.distributed group (or dist.group.WORLD) for SyncBatchNorm semantics
+
+    def forward(self, x, res=None):
+        if self.training:
+            self.num_batches_tracked.add_(1)
+        if (self.fused and self.training and x.is_cuda and x.dim() == 5 and x.shape[1] in ops.BN_RELU_CHANNELS and
+                x.is_contiguous(memory_format=torch.channels_last_3d)):
+            return ops.bn_relu_3d(x, self.weight, self.bias, res, self.running_mean, self.running_var, self.momentum, self.eps,
+                                  self.sync_group)
+        if self.training and self.sync_group is not None:
+            raise RuntimeError("FusedBNReLU3d: synchronised statistics need the fused GPU path (channels_last_3d, 16 channels)")
+        y = F.relu(F.batch_norm(x, self.running_mean, self.running_var, self.weight, self.bias, self.training, self.momentum,
+                                self.eps))
+        return y if res is None else y + res
 
 
 def _up3d(cin, cout, k=3, pad=1, opad=1, stride=2):
@@ -317,7 +349,7 @@ class reg3d(nn.Module):
     permute to (B,G,D,h,w), which is a no-op copy-wise when the volume was written in that layout by
     movedepth_amd.ops.costvol_grouped(layout='bgd')."""
 
-    def __init__(self, in_channels, base_channels, down_size=3):
+    def __init__(self, in_channels, base_channels, down_size=3, fused_bn=False):
         super().__init__()
         c = base_channels
         self.down_size = down_size
@@ -335,6 +367,14 @@ class reg3d(nn.Module):
             self.conv9 = _up3d(4 * c, 2 * c)
         self.conv11 = _up3d(2 * c, c)
         self.prob = nn.Conv3d(c, 1, 3, stride=1, padding=1, bias=False)
+        # the two full-resolution BatchNorm + ReLU (conv0's, and conv11's together with the skip connection): same
+        # state_dict keys (conv0.bn.*, conv11.1.*), fused kernels on the GPU
+        # Opt-in (fused_bn / --hip_bn_relu): inside the training step it measured slower than the library ops.
+        self.fused_bn = bool(fused_bn) and c in ops.BN_RELU_CHANNELS
+        if self.fused_bn:
+            self.conv0.bn = FusedBNReLU3d(c)
+            self.conv11[1] = FusedBNReLU3d(c)
+            self.conv11[2] = nn.Identity()
 
     # MIOpen solver search ("find") only for this module's convolutions: without it the fp32 3-D convs fall back to
     # naive kernels (1.67 s fwd+bwd), with it for every conv of the model the first step takes ~18 min of kernel
@@ -372,7 +412,9 @@ class reg3d(nn.Module):
             # read a planar (`bgd`) or a channels-last volume in place and hand the gradient back in the same layout
             if not (x.is_contiguous() or x.is_contiguous(memory_format=torch.channels_last_3d)):
                 x = x.contiguous(memory_format=torch.channels_last_3d)
-            c0 = F.relu(self.conv0.bn(ops.conv3d_16(x, self.conv0.conv.weight, self.lib_conv0_fwd_dgrad)), inplace=True)
+            c0 = self.conv0.bn(ops.conv3d_16(x, self.conv0.conv.weight, self.lib_conv0_fwd_dgrad))
+            if not self.fused_bn:
+                c0 = F.relu(c0, inplace=True)
         else:
             x = x.contiguous(memory_format=torch.channels_last_3d) if cl else x.contiguous()
             c0 = self.conv0(x)
@@ -385,7 +427,10 @@ class reg3d(nn.Module):
             x = c2 + self.conv9(x)
         else:
             x = c2
-        x = c0 + self.conv11(x)
+        if self.fused_bn:
+            x = self.conv11[1](self.conv11[0](x), res=c0)   # relu(bn(.)) + c0 in one pass
+        else:
+            x = c0 + self.conv11(x)
         # last layer (C -> 1): hand-written kernels instead of the library's GEMM-shaped ones (1177 / 285 / 2568 us
         # fwd / bwd-data / bwd-weight at 6x16x96x48x160 against ~50 us of memory traffic each); other channel counts
         # and the NCDHW mode stay with the library convolution

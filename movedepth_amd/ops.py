@@ -574,6 +574,75 @@ def conv3d_16(x, weight, lib_fwd_dgrad=False):
     return _Conv3d16.apply(x.float(), weight.float(), lib_fwd_dgrad)
 
 
+# --------------------------------------------------------------------------- BatchNorm + ReLU (+ residual), 16 channels
+class _BnRelu3d(torch.autograd.Function):
+    """Training-mode BatchNorm3d + ReLU (+ residual add) over a channels_last_3d (B,16,D,H,W) tensor in 3 + 5 passes
+    (csrc/bnrelu3d.hip).  `group`: a process group to all-reduce the statistics over (SyncBatchNorm semantics) or None."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, res, running_mean, running_var, momentum, eps, group):
+        import torch.distributed as dist
+        x = x.contiguous(memory_format=torch.channels_last_3d)
+        if res is not None:
+            res = res.contiguous(memory_format=torch.channels_last_3d)
+        C = x.shape[1]
+        nvox = x.numel() // C
+        ws = _ws(_lib.load().md_bn_relu_ws_bytes(), x.device)
+        sums = torch.empty(2 * C + 1, device=x.device, dtype=torch.float32)
+        _timed_call("md_bn_relu_stats", _p(x), nvox, C, _p(sums), _p(ws), _stream())
+        sums[2 * C] = float(nvox)
+        if group is not None:
+            dist.all_reduce(sums, group=group)
+        s64 = sums.double()
+        n = s64[2 * C]
+        mean64 = s64[:C] / n
+        var64 = (s64[C:2 * C] / n - mean64 * mean64).clamp_min_(0.0)     # biased, as F.batch_norm in training
+        mean, invstd = mean64.float(), torch.rsqrt(var64 + eps).float()
+        if running_mean is not None:
+            with torch.no_grad():
+                running_mean.lerp_(mean.to(running_mean.dtype), momentum)
+                running_var.lerp_((var64 * (n / (n - 1).clamp_min(1.0))).to(running_var.dtype), momentum)
+        y = torch.empty_like(x, memory_format=torch.channels_last_3d)
+        w, b = weight.float().contiguous(), bias.float().contiguous()
+        _timed_call("md_bn_relu_apply", _p(x), _p(mean), _p(invstd), _p(w), _p(b), _p(res), nvox, C, _p(y), _stream())
+        ctx.save_for_backward(x, mean, invstd, w, b, sums)
+        ctx.group, ctx.has_res = group, res is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        import torch.distributed as dist
+        x, mean, invstd, w, b, fsums = ctx.saved_tensors
+        C = x.shape[1]
+        nvox = x.numel() // C
+        dy = dy.float().contiguous(memory_format=torch.channels_last_3d)
+        ws = _ws(_lib.load().md_bn_relu_ws_bytes(), x.device)
+        sums = torch.empty(2 * C, device=x.device, dtype=torch.float32)
+        _timed_call("md_bn_relu_bwd_reduce", _p(dy), _p(x), _p(mean), _p(invstd), _p(w), _p(b), nvox, C, _p(sums), _p(ws),
+                    _stream())
+        d_beta, d_gamma = sums[:C].clone(), sums[C:].clone()             # local sums (the gradient reducer averages them)
+        n_total = nvox
+        if ctx.group is not None:
+            dist.all_reduce(sums, group=ctx.group)
+            n_total = nvox * dist.get_world_size(ctx.group)
+        dx = torch.empty_like(x, memory_format=torch.channels_last_3d)
+        _timed_call("md_bn_relu_bwd_dx", _p(dy), _p(x), _p(mean), _p(invstd), _p(w), _p(b), _p(sums), n_total, nvox, C, _p(dx),
+                    _stream())
+        return dx, d_gamma, d_beta, (dy if ctx.has_res else None), None, None, None, None, None
+
+
+BN_RELU_CHANNELS = (16,)
+
+
+def bn_relu_3d(x, weight, bias, res=None, running_mean=None, running_var=None, momentum=0.1, eps=1e-5, group=None):
+    """relu(batch_norm(x)) [+ res] in training mode (batch statistics; running statistics updated in place):
+    reference networks/resnet_encoder.py:231 (ConvBnReLU3D), :249-252 + :264 (conv11 and the skip connection).
+    x (B,16,D,H,W) on the GPU, read as channels_last_3d."""
+    if not x.is_cuda or x.shape[1] not in BN_RELU_CHANNELS:
+        raise _lib.MovedepthHipError("bn_relu_3d: needs a GPU tensor with 16 channels, got %s %s" % (x.device, tuple(x.shape)))
+    return _BnRelu3d.apply(x.float(), weight, bias, res, running_mean, running_var, float(momentum), float(eps), group)
+
+
 # --------------------------------------------------------------------------- pose parameters -> 4x4
 class _PoseMatrix(torch.autograd.Function):
     @staticmethod

@@ -97,6 +97,9 @@ class MonodepthOptions:
                             "copy in channels_last: 50.06 vs 51.60 ms per step with it left in NCHW")
         p.add_argument("--bn_counter_on_host", type=int, default=1,
                        help="keep BatchNorm's num_batches_tracked counters in host memory (no GPU kernel per BatchNorm call)")
+        p.add_argument("--hip_bn_relu", type=int, default=0,
+                       help="the 3-D regulariser's two full-resolution BatchNorm+ReLU (+skip add) on the fused kernels.  Off by "
+                            "default: measured slower in the step (49.90, 50.04 ms against 49.26, 49.65 ms with the torch ops)")
         p.add_argument("--fused_adam", type=int, default=1, help="torch's fused Adam kernel on the GPU (0: default implementation)")
         p.add_argument("--sync_bn", type=int, default=1, help="with --ddp: convert BatchNorm to SyncBatchNorm (reference)")
         p.add_argument("--grad_bucket_mb", type=float, default=32.0, help="with --ddp: all-reduce bucket size")

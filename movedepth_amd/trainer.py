@@ -71,7 +71,7 @@ class Trainer:
         self.models["mask_cnn"] = networks.UncertNet()
         self.models["mvs_encoder"] = networks.FPN4(base_channels=8, scale=opt.prior_scale, dcn=opt.dcn)
         if opt.num_depth_bins >= 8:
-            self.models["reg3d"] = networks.reg3d(opt.reg3d_c, opt.reg3d_c, down_size=3)
+            self.models["reg3d"] = networks.reg3d(opt.reg3d_c, opt.reg3d_c, down_size=3, fused_bn=bool(opt.hip_bn_relu))
         else:
             self.models["reg3d"] = networks.reg2d(opt.reg3d_c, opt.reg3d_c)
         mvs = ["mask_cnn", "mvs_encoder", "reg3d"]
@@ -102,12 +102,18 @@ class Trainer:
                 # 2-D networks in channels_last: same results (outputs equal to 1e-7, tests/test_trainer_parity.py), the
                 # library's NHWC kernels without the NCHW<->NHWC transposes around them; -2.1 ms per step at config 2
                 self.models[k] = self.models[k].to(memory_format=torch.channels_last)
+        for m in self.models.values():
+            for mod in m.modules():
+                if isinstance(mod, networks.FusedBNReLU3d):
+                    if opt.ddp and opt.sync_bn and not share_gpu:   # what convert_sync_batchnorm does for the others
+                        mod.sync_group = dist.group.WORLD
         if opt.bn_counter_on_host:
             # BatchNorm's num_batches_tracked += 1 is a GPU kernel per BatchNorm call (115 per step, ~0.5 ms) for a counter
             # nothing on the device reads (momentum is fixed): keep the counters in host memory.  Same state_dict.
             for m in self.models.values():
                 for mod in m.modules():
-                    if isinstance(mod, torch.nn.modules.batchnorm._BatchNorm) and mod.num_batches_tracked is not None:
+                    if isinstance(mod, (torch.nn.modules.batchnorm._BatchNorm, networks.FusedBNReLU3d)) and \
+                            mod.num_batches_tracked is not None:
                         mod.num_batches_tracked = mod.num_batches_tracked.cpu()
         for k in main:
             self.parameters_to_train += list(self.models[k].parameters())

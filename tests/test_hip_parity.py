@@ -633,10 +633,19 @@ def test_conv0_full_size_vs_library(ops):
 def _reg3d_run(net, vol):
     """forward + backward of reg3d; returns (logits, d_volume, d_conv0_weight) and the ReLU masks (sign of every
     BatchNorm output)."""
+    from movedepth_amd import networks
     masks, hooks = [], []
+
+    def fused_mask(mod, i, o):  # FusedBNReLU3d returns the activation (+ skip): recompute the pre-activation's sign
+        with torch.no_grad():
+            z = torch.nn.functional.batch_norm(i[0].detach(), None, None, mod.weight, mod.bias, True, 0.0, mod.eps)
+        masks.append((z > 0).cpu())
+
     for m in net.modules():
         if isinstance(m, torch.nn.BatchNorm3d):
             hooks.append(m.register_forward_hook(lambda mod, i, o: masks.append((o.detach() > 0).cpu())))
+        elif isinstance(m, networks.FusedBNReLU3d):
+            hooks.append(m.register_forward_hook(fused_mask))
     net.zero_grad()
     v = vol.detach().requires_grad_(True)  # keeps the strides
     o = net(v)
@@ -722,3 +731,70 @@ def test_pose_matrix_matches_torch_form_and_layers_dispatch(ops):
         assert_close(host(a_g.grad)[1:], a_c.grad.numpy()[1:], rtol=1e-5, what="d_axisangle")  # [0]: torch gives nan/0 at v = 0
         assert_close(host(t_g.grad), t_c.grad.numpy(), rtol=1e-5, what="d_translation")
     np.testing.assert_allclose(host(Tg)[0, :3, :3] if inv else host(Tg)[0, :3, :3], np.eye(3), atol=1e-7)
+
+
+# ------------------------------------------------------------------ fused BatchNorm + ReLU (+ residual), 16 channels
+@pytest.mark.parametrize("shape,with_res", [((2, 16, 5, 7, 9), False), ((2, 16, 5, 7, 9), True), ((1, 16, 1, 1, 3), True),
+                                             ((6, 16, 96, 48, 160), True)])
+def test_bn_relu_vs_torch(ops, shape, with_res):
+    """relu(batch_norm(x)) [+ res] in training mode against the torch ops the reference module uses (BatchNorm3d + ReLU,
+    resnet_encoder.py:231 / :249-252, skip add :264): output, all gradients, running statistics.  The last shape is
+    BASELINE config 2."""
+    torch.manual_seed(13)
+    x = _cl3d(torch.randn(*shape, device="cuda") * 1.5 + 0.3)
+    res = _cl3d(torch.randn(*shape, device="cuda")) if with_res else None
+    gamma, beta = torch.rand(16, device="cuda") + 0.5, torch.randn(16, device="cuda") * 0.2
+    gy = _cl3d(torch.randn(*shape, device="cuda"))
+    rm_a, rv_a = torch.zeros(16, device="cuda"), torch.ones(16, device="cuda")
+    rm_b, rv_b = rm_a.clone(), rv_a.clone()
+    xa, ga, ba = x.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    ra = res.clone().requires_grad_(True) if with_res else None
+    ya = ops.bn_relu_3d(xa, ga, ba, ra, rm_a, rv_a, 0.1, 1e-5)
+    ya.backward(gy)
+    # reference in fp64 (same torch ops): at 70 M elements a ReLU pre-activation within fp32 rounding of zero is expected
+    # (one such element moves the norm-wise error of d_x to 1.7e-4), so d_x allows a 1e-6 fraction of outlier elements
+    xb, gb, bb = (t.double().clone().requires_grad_(True) for t in (x, gamma, beta))
+    rb = res.double().clone().requires_grad_(True) if with_res else None
+    rm_b, rv_b = rm_b.double(), rv_b.double()
+    yb = torch.relu(torch.nn.functional.batch_norm(xb, rm_b, rv_b, gb, bb, True, 0.1, 1e-5))
+    if with_res:
+        yb = yb + rb
+    yb.backward(gy.double())
+    n = x.numel() // 16
+    if n > 1:
+        assert_close(host(ya), host(yb), what="y")
+        assert_close_knife_edge(host(xa.grad), host(xb.grad), rtol=2e-4 if n < 100 else 1e-4, max_outlier_frac=1e-6 if n > 1e5 else 0.0,
+                                what="d_x")
+        # d_gamma / d_beta are sums of n random-sign terms here (gy is white noise), i.e. ~sqrt(n) in size, so the handful
+        # of ReLU decisions that differ from fp64 at 70 M elements (expected ~6: 70e6 * density(0) * 2e-7) show up at
+        # ~6^0.5 * 0.25 / 6000 = 1e-4 of the norm; measured 1.15e-4.  Small shapes have no such elements.
+        rt = 5e-4 if n > 1e5 else 1e-4
+        assert_close(host(ga.grad), host(gb.grad), rtol=rt, what="d_gamma")
+        assert_close(host(ba.grad), host(bb.grad), rtol=rt, what="d_beta")
+        assert_close(host(rm_a), host(rm_b), rtol=1e-5, what="running_mean")
+        assert_close(host(rv_a), host(rv_b), rtol=1e-5, what="running_var")
+    if with_res:
+        assert torch.equal(ra.grad, gy)
+
+
+def test_reg3d_fused_bn_paths_agree(ops):
+    """reg3d with the fused BatchNorm+ReLU(+skip) kernels against the same module on torch ops: same state_dict keys,
+    logits at 1e-4, gradients at 1e-4 when every ReLU decision agrees (see test_reg3d_conv0_paths_agree)."""
+    from movedepth_amd import networks
+    torch.manual_seed(4)
+    net = networks.reg3d(16, 16, 3, fused_bn=True).cuda().to(memory_format=torch.channels_last_3d)
+    assert set(net.state_dict().keys()) == set(networks.reg3d(16, 16, 3).state_dict().keys())
+    keys = set(net.state_dict().keys())
+    assert {"conv0.bn.weight", "conv0.bn.running_var", "conv0.bn.num_batches_tracked", "conv11.1.weight", "conv11.1.bias",
+            "conv11.1.running_mean"} <= keys and not any(k.startswith("conv11.2") for k in keys)
+    vol = torch.randn(2, 16, 24, 32, 16, device="cuda").permute(0, 1, 4, 2, 3)   # channels-last volume
+    runs = []
+    for fused in (True, False):
+        for m in net.modules():
+            if isinstance(m, networks.FusedBNReLU3d):
+                m.fused = fused
+        runs.append(_reg3d_run(net, vol))
+    (out, _), (ref_out, _) = runs
+    assert_close(out[0], ref_out[0], what="logits")
+    for a, b, what in zip(out[1:], ref_out[1:], ("d_volume", "d_conv0_weight")):
+        assert_close(a, b, rtol=5e-3, what=what)   # masks of the fused layers are not hookable: loose bound, see docstring
