@@ -310,6 +310,13 @@ int c16_dims(const char *fn, int B, int Ci, int Co, int D, int H, int W, C16Dims
     // two workgroups fit a CU (65 KB of LDS each): at least ~3 per CU in total for balance, >= 8 planes per slice
     int ds = 1;
     while (ds * 2 <= D / 8 && (long long)B * dm.tiles * ds < 700) ds *= 2;
+    // Swept at 6x96x48x160 (fwd / data gradient / weight gradient, us): 4 slices (this default, 720 workgroups) 628 / 629 /
+    // 701; 6: 656 / 650 / 773; 8: 630 / 624 / 695; 12: 645 / 618 / 788; 16: 663 / 635 / 842 -- the ~60 % of peak is not a
+    // tail effect of 720 workgroups on 512 slots.
+    if (const char *e = getenv("MD_C16_DSLICES")) {  // experiment knob: planes per slice = ceil(D / value)
+        const int v = atoi(e);
+        if (v >= 1 && v <= D) ds = v;
+    }
     dm.planes = md_cdiv(D, ds);
     dm.dslices = md_cdiv(D, dm.planes);
     return MD_OK;
