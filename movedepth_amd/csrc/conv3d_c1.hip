@@ -25,12 +25,6 @@
 
 namespace {
 
-// waves per SIMD the forward kernel is compiled for (its 27 x 4 weights + 24 sums + 24 prefetch registers want > 256
-// VGPRs; at 2 the compiler spills 88 of them)
-#ifndef MD_C1_FWD_WAVES
-#define MD_C1_FWD_WAVES 1
-#endif
-
 constexpr int TH = 8, TW = 32, HW_ = TW + 2, HH_ = TH + 2, CELLS = HH_ * HW_;  // tile and its 1-voxel halo
 
 struct C1Dims {
@@ -58,7 +52,7 @@ __device__ __forceinline__ float quad_sum(float v) {
 
 // ------------------------------------------------------------------------------------------------ forward
 template <int QN>
-__global__ __launch_bounds__(256, MD_C1_FWD_WAVES) void conv3d_c1_fwd_kernel(const float *__restrict__ x, const float *__restrict__ wt,
+__global__ __launch_bounds__(256) void conv3d_c1_fwd_kernel(const float *__restrict__ x, const float *__restrict__ wt,
                                                             long long wsk, long long wsc, float *__restrict__ y,
                                                             const C1Dims dm) {
     constexpr int NV = QN;                     // voxels per thread: 256 voxels / (256 / QN) voxel lanes
@@ -69,11 +63,13 @@ __global__ __launch_bounds__(256, MD_C1_FWD_WAVES) void conv3d_c1_fwd_kernel(con
     int b, ty0, tx0, d0, d1;
     c1_item(dm, blockIdx.x, b, ty0, tx0, d0, d1);
     if (d0 >= d1) return;
-    float4 wr[27];
-#pragma unroll
-    for (int k = 0; k < 27; ++k) {
-        const float *p = wt + k * wsk + (long long)(q * 4) * wsc;
-        wr[k] = make_float4(p[0], p[wsc], p[2 * wsc], p[3 * wsc]);
+    // weights in LDS, [tap][quad] float4: with them in registers (27 x 4 per thread) the kernel needed 338 VGPRs = one wave
+    // per SIMD; read per tap inside a tap-outer / voxel-inner loop they cost 3 registers at a time
+    __shared__ float4 wsh[27 * QN];
+    if (tid < 27 * QN) {
+        const int k = tid / QN, qq = tid % QN;
+        const float *p = wt + k * wsk + (long long)(qq * 4) * wsc;
+        wsh[tid] = make_float4(p[0], p[wsc], p[2 * wsc], p[3 * wsc]);
     }
     const size_t plane = (size_t)dm.H * dm.W;
     const float4 *xb = reinterpret_cast<const float4 *>(x) + (size_t)b * dm.D * plane * QN;
@@ -109,24 +105,29 @@ __global__ __launch_bounds__(256, MD_C1_FWD_WAVES) void conv3d_c1_fwd_kernel(con
     for (int p = p0; p < p1; ++p) {
         if (p + 1 < p1) fetch(p + 1);
         const float4 *tl = tile[p & 1];
+        // the 9 in-plane taps as a ROLLED loop: fully unrolled, the compiler hoists all 63 LDS reads of a plane step and
+        // needs 370 VGPRs (one wave per SIMD; neither a sched_barrier nor a compiler memory barrier per tap stops it);
+        // rolled it is 116
+#pragma unroll 1
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll 1
+            for (int kw = 0; kw < 3; ++kw) {
+                float4 w3[3];
 #pragma unroll
-        for (int j = 0; j < NV; ++j) {
-            const int vid = j * VL + vl, ty = vid / TW, tx = vid % TW;
+                for (int kd = 0; kd < 3; ++kd) w3[kd] = wsh[((kd * 3 + kh) * 3 + kw) * QN + q];
 #pragma unroll
-            for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-                for (int kw = 0; kw < 3; ++kw) {
+                for (int j = 0; j < NV; ++j) {
+                    const int vid = j * VL + vl, ty = vid / TW, tx = vid % TW;
                     const float4 v = tl[((ty + kh) * HW_ + tx + kw) * QN + q];
 #pragma unroll
                     for (int kd = 0; kd < 3; ++kd) {  // plane p is tap kd of output d = p + 1 - kd
-                        const float4 w4 = wr[(kd * 3 + kh) * 3 + kw];
-                        acc[j][kd].x = fmaf(v.x, w4.x, acc[j][kd].x);
-                        acc[j][kd].y = fmaf(v.y, w4.y, acc[j][kd].y);
-                        acc[j][kd].x = fmaf(v.z, w4.z, acc[j][kd].x);
-                        acc[j][kd].y = fmaf(v.w, w4.w, acc[j][kd].y);
+                        acc[j][kd].x = fmaf(v.x, w3[kd].x, acc[j][kd].x);
+                        acc[j][kd].y = fmaf(v.y, w3[kd].y, acc[j][kd].y);
+                        acc[j][kd].x = fmaf(v.z, w3[kd].z, acc[j][kd].x);
+                        acc[j][kd].y = fmaf(v.w, w3[kd].w, acc[j][kd].y);
                     }
                 }
-        }
+            }
         // output plane p-1 is complete (its kd=2 tap was plane p); the last plane of the volume completes plane p too
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(256) void conv3d_c1_bwd_data_kernel(const float *__
         gy_stash(R.slot(d + 1), r);
         __syncthreads();
         if (d + 1 < d1) gy_fetch(gyb, dm, d + 2, ty0, tx0, r);
-#pragma unroll
+#pragma unroll 1  // rolled: one voxel's 27 taps at a time keeps the register count (and with it the occupancy) in check
         for (int j = 0; j < NV; ++j) {
             const int vid = j * VL + vl, ty = vid / TW, tx = vid % TW;
             float4 a = make_float4(0.f, 0.f, 0.f, 0.f);

@@ -191,15 +191,19 @@ __global__ __launch_bounds__(256, 2) void conv3d_c16_bwd_weight_kernel(const flo
 __global__ __launch_bounds__(256) void conv3d_c16_bwd_weight_finish_kernel(const float *__restrict__ partial, int nwg,
                                                                            long long s_co, long long s_ci, long long s_k,
                                                                            float *__restrict__ dwt) {
-    __shared__ double sh[4][64];
-    const int ol = threadIdx.x & 63, seg = threadIdx.x >> 6;
-    const int o = blockIdx.x * 64 + ol;  // element of [k][lane][r]
+    // block = 16 outputs x 16 segments of the workgroup list (432 blocks; 64 outputs x 4 segments on 108 blocks took 47 us
+    // for 20 MB of partials)
+    __shared__ double sh[16][16];
+    const int ol = threadIdx.x & 15, seg = threadIdx.x >> 4;
+    const int o = blockIdx.x * 16 + ol;  // element of [k][lane][r]
     double s = 0.0;
-    for (int i = seg; i < nwg; i += 4) s += (double)partial[(size_t)i * (NTAP * 256) + o];
+    for (int i = seg; i < nwg; i += 16) s += (double)partial[(size_t)i * (NTAP * 256) + o];
     sh[seg][ol] = s;
     __syncthreads();
     if (seg == 0) {
-        const double t = (sh[0][ol] + sh[1][ol]) + (sh[2][ol] + sh[3][ol]);
+        double t = 0.0;
+#pragma unroll
+        for (int k2 = 0; k2 < 16; ++k2) t += sh[k2][ol];
         const int k = o >> 8, lane = (o >> 2) & 63, r = o & 3;
         const int ci = 4 * (lane >> 4) + r, co = lane & 15;
         dwt[co * s_co + ci * s_ci + k * s_k] = (float)t;
@@ -377,7 +381,7 @@ int md_conv3d_c16_bwd_weight(const float *x, int x_planar, const float *gy, floa
     if (x_planar) hipLaunchKernelGGL(conv3d_c16_bwd_weight_kernel<true>, dim3(nwg), dim3(256), 0, s, x, gy, partial, dm);
     else hipLaunchKernelGGL(conv3d_c16_bwd_weight_kernel<false>, dim3(nwg), dim3(256), 0, s, x, gy, partial, dm);
     MD_CHECK_LAUNCH("md_conv3d_c16_bwd_weight");
-    hipLaunchKernelGGL(conv3d_c16_bwd_weight_finish_kernel, dim3(NTAP * 256 / 64), dim3(256), 0, s, partial, nwg, dw_stride_co,
+    hipLaunchKernelGGL(conv3d_c16_bwd_weight_finish_kernel, dim3(NTAP * 256 / 16), dim3(256), 0, s, partial, nwg, dw_stride_co,
                        dw_stride_ci, dw_stride_k, dwt);
     MD_CHECK_LAUNCH("md_conv3d_c16_bwd_weight(finish)");
     return MD_OK;
