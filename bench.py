@@ -208,7 +208,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(opt)
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.destroy_process_group()
 
 
