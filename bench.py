@@ -134,7 +134,10 @@ def main():
     import numpy as np
 
     np.random.seed(1234 + rank)
-    trainer = Trainer(opt)
+    import contextlib
+
+    with contextlib.redirect_stdout(sys.stderr):  # the trainer's banner (reference trainer.py:163-165) must not share
+        trainer = Trainer(opt)                     # stdout with the one JSON line
     trainer.set_train()
     dev = trainer.device
     inputs = make_inputs(opt.batch_size, opt.height, opt.width, opt.frame_ids, seed=rank, device=dev)  # resident in HBM
