@@ -142,9 +142,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_c16_bwd_weight_kernel(const flo
         const float *s0 = ring + ((d + 2) % 3) * PLANE_F + chofs;  // planes d-1, d, d+1
         const float *s1 = ring + (d % 3) * PLANE_F + chofs;
         const float *s2 = ring + ((d + 1) % 3) * PLANE_F + chofs;
-#pragma unroll 1
-        for (int g = 0; g < 16; ++g) {
-            const float gnext = gy_load(d, (g + 1) & 15);  // one group ahead (the wrap-around load is discarded)
+        // operands of group g+1 are read from LDS while the 27 MFMAs of group g run (one group ahead, like gy)
+        auto a_load = [&](int g, float (&av)[NTAP]) {
             const int cell = ((2 * wave + (g >> 3)) * HW_ + (g & 7) * 4 + v) * CS;  // this lane's voxel, halo origin
 #pragma unroll
             for (int kd = 0; kd < 3; ++kd) {
@@ -152,12 +151,20 @@ __global__ __launch_bounds__(256, 2) void conv3d_c16_bwd_weight_kernel(const flo
 #pragma unroll
                 for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-                    for (int kw = 0; kw < 3; ++kw) {
-                        const float a = sl[(kh * HW_ + kw) * CS];
-                        const int k = (kd * 3 + kh) * 3 + kw;
-                        acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, gcur, acc[k], 0, 0, 0);
-                    }
+                    for (int kw = 0; kw < 3; ++kw) av[(kd * 3 + kh) * 3 + kw] = sl[(kh * HW_ + kw) * CS];
             }
+        };
+        float acur[NTAP];
+        a_load(0, acur);
+#pragma unroll 1
+        for (int g = 0; g < 16; ++g) {
+            const float gnext = gy_load(d, (g + 1) & 15);  // one group ahead (the wrap-around load is discarded)
+            float anext[NTAP];
+            a_load((g + 1) & 15, anext);
+#pragma unroll
+            for (int k = 0; k < NTAP; ++k) acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(acur[k], gcur, acc[k], 0, 0, 0);
+#pragma unroll
+            for (int k = 0; k < NTAP; ++k) acur[k] = anext[k];
             gcur = gnext;
         }
         __syncthreads();  // slot (d+2)%3 == (d-1)%3 is rewritten at the top of the next step
