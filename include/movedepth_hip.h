@@ -20,6 +20,7 @@
 #define MOVEDEPTH_HIP_H
 
 #include <stddef.h>
+#include <stdint.h>
 
 #ifdef __cplusplus
 extern "C" {
@@ -71,6 +72,27 @@ int md_costvol_bwd(const float *gout, long long g_sb, long long g_sd, long long 
                    const float *src, const float *K, const float *invK, const float *pose, const float *hyp,
                    const float *prior, const float *ztrans, float scale_fac, int sched_type, int B, int C, int G,
                    int h, int w, int D, float *d_ref, float *d_src, md_stream_t stream);
+
+/* The same two entry points with 2-byte feature maps and volume (BASELINE configs 4 and 5: bf16 / fp16 mixed precision;
+ * SURVEY 8d table rows 4-5): ref, src, out and gout are bf16 (`_bf16`) or IEEE half (`_f16`) bit patterns (uint16_t
+ * here, no vendor types in the ABI); arithmetic, hypotheses, poses and the gradients d_ref / d_src stay fp32; strides
+ * are in elements.  Half the volume bytes (147.5 MB algorithmic per launch at config 2's shape instead of 295.1). */
+int md_costvol_fwd_bf16(const uint16_t *ref, const uint16_t *src, const float *K, const float *invK, const float *pose,
+                        const float *hyp, const float *prior, const float *ztrans, float scale_fac, int sched_type, int B,
+                        int C, int G, int h, int w, int D, uint16_t *out, long long out_sb, long long out_sd,
+                        long long out_sg, long long out_sp, md_stream_t stream);
+int md_costvol_bwd_bf16(const uint16_t *gout, long long g_sb, long long g_sd, long long g_sg, long long g_sp,
+                        const uint16_t *ref, const uint16_t *src, const float *K, const float *invK, const float *pose,
+                        const float *hyp, const float *prior, const float *ztrans, float scale_fac, int sched_type, int B,
+                        int C, int G, int h, int w, int D, float *d_ref, float *d_src, md_stream_t stream);
+int md_costvol_fwd_f16(const uint16_t *ref, const uint16_t *src, const float *K, const float *invK, const float *pose,
+                       const float *hyp, const float *prior, const float *ztrans, float scale_fac, int sched_type, int B,
+                       int C, int G, int h, int w, int D, uint16_t *out, long long out_sb, long long out_sd,
+                       long long out_sg, long long out_sp, md_stream_t stream);
+int md_costvol_bwd_f16(const uint16_t *gout, long long g_sb, long long g_sd, long long g_sg, long long g_sp,
+                       const uint16_t *ref, const uint16_t *src, const float *K, const float *invK, const float *pose,
+                       const float *hyp, const float *prior, const float *ztrans, float scale_fac, int sched_type, int B,
+                       int C, int G, int h, int w, int D, float *d_ref, float *d_src, md_stream_t stream);
 
 /* ---- frame-confidence fusion --------------------------------------------------------------
  * trainer.py:349-363: w_f = max_G softmax_G(mean_D vol_f); out = sum_f w_f vol_f / (1e-8 + sum_f w_f).

@@ -28,7 +28,55 @@
 
 #include "md_common.hpp"
 
+// Element type of the feature maps (ref, src) and of the volume (out, gout); everything in between is fp32.
+// MD_CV_IO = 0: float (the default build, entry points md_costvol_fwd / md_costvol_bwd);
+//            1: bf16, 2: fp16 -- the Makefile compiles this file again with these (entry points *_bf16 / *_f16),
+//               BASELINE configs 4 and 5: half the volume bytes, same arithmetic.  d_ref / d_src stay fp32.
+#ifndef MD_CV_IO
+#define MD_CV_IO 0
+#endif
+#if MD_CV_IO == 1
+#include <hip/hip_bf16.h>
+typedef __hip_bfloat16 io_t;
+typedef uint16_t abi_io_t;  // the ABI carries bit patterns, no vendor types
+#define MD_CV_NAME(x) x##_bf16
+#elif MD_CV_IO == 2
+#include <hip/hip_fp16.h>
+typedef __half io_t;
+typedef uint16_t abi_io_t;
+#define MD_CV_NAME(x) x##_f16
+#else
+typedef float io_t;
+typedef float abi_io_t;
+#define MD_CV_NAME(x) x
+#endif
+#define MD_CV_STR2(x) #x
+#define MD_CV_STR(x) MD_CV_STR2(x)
+
 namespace {
+
+#if MD_CV_IO == 1
+__device__ __forceinline__ float ldio(const io_t *p) { return __bfloat162float(*p); }
+__device__ __forceinline__ void stio(io_t *p, float v) { *p = __float2bfloat16(v); }
+#elif MD_CV_IO == 2
+__device__ __forceinline__ float ldio(const io_t *p) { return __half2float(*p); }
+__device__ __forceinline__ void stio(io_t *p, float v) { *p = __float2half(v); }
+#else
+// plain expressions, not functions, in the fp32 build: through a (non-restrict) function parameter the compiler scheduled
+// the planar forward kernel 5 % slower
+#define ldio(...) (*(__VA_ARGS__))
+#define stio(p, v) (*(p) = (v))
+#endif
+// four consecutive volume elements (p 16-byte aligned for float, 8-byte for the half types)
+#if MD_CV_IO == 0
+#define stio4(p, v) (*reinterpret_cast<float4 *>(p) = (v))
+#else
+__device__ __forceinline__ void stio4(io_t *p, float4 v) {
+    io_t t[4];
+    stio(t, v.x); stio(t + 1, v.y); stio(t + 2, v.z); stio(t + 3, v.w);
+    *reinterpret_cast<uint2 *>(p) = *reinterpret_cast<const uint2 *>(t);
+}
+#endif
 
 // true: follow Project3D's operation order step by step (P @ (depth * ray), /(w-1), -0.5, *2, then grid_sample's
 // un-normalise); false: the algebraically identical 3-FMA form.  The two differ by a few ulp of the pixel coordinate
@@ -142,7 +190,7 @@ struct Walk {
 
 // Tap outside the staged window: zero when all four taps miss the image, else bounds-checked global loads.
 template <int CPW, int N>
-__device__ __noinline__ vecf<CPW> sample_slow(const float *__restrict__ srcb, int h, int w, int G, int gbase, int x0,
+__device__ __noinline__ vecf<CPW> sample_slow(const io_t *__restrict__ srcb, int h, int w, int G, int gbase, int x0,
                                                int y0, float w00, float w01, float w10, float w11) {
     vecf<CPW> S = 0.f;
     if (x0 < -1 || x0 >= w || y0 < -1 || y0 >= h) return S;
@@ -151,12 +199,12 @@ __device__ __noinline__ vecf<CPW> sample_slow(const float *__restrict__ srcb, in
     const bool vx0 = x0 >= 0, vx1 = x1 < w, vy0 = y0 >= 0, vy1 = y1 < h;
 #pragma unroll
     for (int k = 0; k < CPW; ++k) {
-        const float *pl = srcb + (size_t)Slots<CPW / N, N>::channel(k, G, gbase) * hw;
+        const io_t *pl = srcb + (size_t)Slots<CPW / N, N>::channel(k, G, gbase) * hw;
         float s = 0.f;
-        if (vx0 && vy0) s += pl[y0 * w + x0] * w00;
-        if (vx1 && vy0) s += pl[y0 * w + x1] * w01;
-        if (vx0 && vy1) s += pl[y1 * w + x0] * w10;
-        if (vx1 && vy1) s += pl[y1 * w + x1] * w11;
+        if (vx0 && vy0) s += ldio(pl + y0 * w + x0) * w00;
+        if (vx1 && vy0) s += ldio(pl + y0 * w + x1) * w01;
+        if (vx0 && vy1) s += ldio(pl + y1 * w + x0) * w10;
+        if (vx1 && vy1) s += ldio(pl + y1 * w + x1) * w11;
         S[k] = s;
     }
     return S;
@@ -183,7 +231,7 @@ __device__ __noinline__ void scatter_slow(float *__restrict__ dsrcb, int h, int 
 // Bilinear samples of the CPW staged channels at tap t ('zeros' padding comes from the zero-filled window).
 template <int CPW, int N, int TW>
 __device__ __forceinline__ vecf<CPW> sample_window(const float4 *win, const Tap4 &t, int ox, int oy,
-                                                   const float *__restrict__ srcb, int h, int w, int G, int gbase) {
+                                                   const io_t *__restrict__ srcb, int h, int w, int G, int gbase) {
     using T = Tile<TW, CPW>;
     constexpr int QPP = CPW / 4;
     const int lx = t.x0 - ox, ly = t.y0 - oy;
@@ -255,7 +303,7 @@ __device__ __forceinline__ void groups_from_window(const float4 *wp, const Tap4 
 
 // Slow path (tap outside the staged window): group outputs from bounds-checked global loads.
 template <int GS, int N>
-__device__ __forceinline__ void groups_from_global(const float *__restrict__ srcb, int h, int w, int G, int gbase, const Tap4 &t,
+__device__ __forceinline__ void groups_from_global(const io_t *__restrict__ srcb, int h, int w, int G, int gbase, const Tap4 &t,
                                                    const vecf<GS * N> &rf, float (&og)[GS]) {
     using SL = Slots<GS, N>;
     const vecf<GS * N> S = sample_slow<GS * N, N>(srcb, h, w, G, gbase, t.x0, t.y0, t.w00, t.w01, t.w10, t.w11);
@@ -271,7 +319,7 @@ __device__ __forceinline__ void groups_from_global(const float *__restrict__ src
 // Tile set-up shared by forward and backward: the thread's pixel and walk state, the window origin, and the
 // staged source window.  Returns false for threads outside the image (they still helped stage the window).
 template <int GS, int N, int TW, bool FUSED>
-__device__ __forceinline__ bool tile_setup(const float *__restrict__ src, const float *__restrict__ K,
+__device__ __forceinline__ bool tile_setup(const io_t *__restrict__ src, const float *__restrict__ K,
                                            const float *__restrict__ invK, const float *__restrict__ pose,
                                            const float *__restrict__ hyp, const float *__restrict__ prior,
                                            const float *__restrict__ ztrans, const CvDims &dm, const Seg &sg, float4 *win,
@@ -339,7 +387,7 @@ __device__ __forceinline__ bool tile_setup(const float *__restrict__ src, const 
     // stage the window: consecutive threads -> consecutive columns (coalesced per channel plane).  Four quads
     // (16 loads) are issued before the first LDS write so the L2 round trips overlap instead of queueing
     // (the staging loop used to be ~a quarter of the kernel: 15 dependent round trips per workgroup).
-    const float *srcb = src + (size_t)b * dm.C * hw;
+    const io_t *srcb = src + (size_t)b * dm.C * hw;
     constexpr int NQ = T::WP * QPP, NIT = (NQ + 255) / 256, UNR = 4;
 #pragma unroll
     for (int it0 = 0; it0 < NIT; it0 += UNR) {
@@ -355,10 +403,10 @@ __device__ __forceinline__ bool tile_setup(const float *__restrict__ src, const 
             dst[u] = (it0 + u < NIT && idx < NQ) ? q * T::WP + wy * T::WW + wx : -1;
             if (dst[u] >= 0 && sx >= 0 && sx < dm.w && sy >= 0 && sy < dm.h) {
                 const size_t o = (size_t)sy * dm.w + sx;
-                v[u].x = srcb[(size_t)Slots<GS, N>::channel(q * 4 + 0, dm.G, gbase) * hw + o];
-                v[u].y = srcb[(size_t)Slots<GS, N>::channel(q * 4 + 1, dm.G, gbase) * hw + o];
-                v[u].z = srcb[(size_t)Slots<GS, N>::channel(q * 4 + 2, dm.G, gbase) * hw + o];
-                v[u].w = srcb[(size_t)Slots<GS, N>::channel(q * 4 + 3, dm.G, gbase) * hw + o];
+                v[u].x = ldio(srcb + (size_t)Slots<GS, N>::channel(q * 4 + 0, dm.G, gbase) * hw + o);
+                v[u].y = ldio(srcb + (size_t)Slots<GS, N>::channel(q * 4 + 1, dm.G, gbase) * hw + o);
+                v[u].z = ldio(srcb + (size_t)Slots<GS, N>::channel(q * 4 + 2, dm.G, gbase) * hw + o);
+                v[u].w = ldio(srcb + (size_t)Slots<GS, N>::channel(q * 4 + 3, dm.G, gbase) * hw + o);
             }
         }
 #pragma unroll
@@ -370,11 +418,11 @@ __device__ __forceinline__ bool tile_setup(const float *__restrict__ src, const 
 }
 
 template <int GS, int N, int TW, bool FUSED>
-__global__ __launch_bounds__(256) void costvol_fwd_kernel(const float *__restrict__ ref, const float *__restrict__ src,
+__global__ __launch_bounds__(256) void costvol_fwd_kernel(const io_t *__restrict__ ref, const io_t *__restrict__ src,
                                                           const float *__restrict__ K, const float *__restrict__ invK,
                                                           const float *__restrict__ pose, const float *__restrict__ hyp,
                                                           const float *__restrict__ prior,
-                                                          const float *__restrict__ ztrans, float *__restrict__ out,
+                                                          const float *__restrict__ ztrans, io_t *__restrict__ out,
                                                           const CvDims dm) {
     constexpr int CPW = GS * N, QPP = CPW / 4;
     using T = Tile<TW, CPW>;
@@ -391,14 +439,14 @@ __global__ __launch_bounds__(256) void costvol_fwd_kernel(const float *__restric
     const bool valid = tile_setup<GS, N, TW, FUSED>(src, K, invK, pose, hyp, prior, ztrans, dm, sg, win, bb, itv, wk, b,
                                                     gbase, p, d0, d1, ox, oy);
     const size_t hw = (size_t)dm.h * dm.w;
-    const float *srcb = src + (size_t)b * dm.C * hw;
+    const io_t *srcb = src + (size_t)b * dm.C * hw;
     vecf<CPW> rf = 0.f;  // ref features with the 1/N of the group mean folded in
     if (valid) {
 #pragma unroll
         for (int k = 0; k < CPW; ++k)
-            rf[k] = ref[((size_t)b * dm.C + Slots<GS, N>::channel(k, dm.G, gbase)) * hw + p] * (1.f / (float)N);
+            rf[k] = ldio(ref + ((size_t)b * dm.C + Slots<GS, N>::channel(k, dm.G, gbase)) * hw + p) * (1.f / (float)N);
     }
-    float *outp = out + (size_t)b * dm.sb + (size_t)gbase * dm.sg + (size_t)d0 * dm.sd + (size_t)p * dm.sp;
+    io_t *outp = out + (size_t)b * dm.sb + (size_t)gbase * dm.sg + (size_t)d0 * dm.sd + (size_t)p * dm.sp;
     float dnext = valid ? wk.hypothesis(itv, d0) : 1.f;
     for (int d = d0; valid && d < d1; ++d) {
         const float dep = dnext;
@@ -411,7 +459,7 @@ __global__ __launch_bounds__(256) void costvol_fwd_kernel(const float *__restric
         else
             groups_from_global<GS, N>(srcb, dm.h, dm.w, dm.G, gbase, t, rf, og);
 #pragma unroll
-        for (int j = 0; j < GS; ++j) outp[(size_t)j * dm.sg] = og[j];
+        for (int j = 0; j < GS; ++j) stio(outp + (size_t)j * dm.sg, og[j]);
         outp += dm.sd;
     }
     __syncthreads();  // the window is restaged by the next segment
@@ -425,11 +473,11 @@ __global__ __launch_bounds__(256) void costvol_fwd_kernel(const float *__restric
 // order: lane l of store k writes the 16 bytes at linear position (k*64 + l) of the wave's pixel-major block --
 // consecutive lanes, consecutive addresses, 1 KB per instruction.
 template <int GS, int N, int TW, bool FUSED>
-__global__ __launch_bounds__(256) void costvol_fwd_nhwc_kernel(const float *__restrict__ ref, const float *__restrict__ src,
+__global__ __launch_bounds__(256) void costvol_fwd_nhwc_kernel(const io_t *__restrict__ ref, const io_t *__restrict__ src,
                                                                const float *__restrict__ K, const float *__restrict__ invK,
                                                                const float *__restrict__ pose, const float *__restrict__ hyp,
                                                                const float *__restrict__ prior,
-                                                               const float *__restrict__ ztrans, float *__restrict__ out,
+                                                               const float *__restrict__ ztrans, io_t *__restrict__ out,
                                                                const CvDims dm) {
     constexpr int CPW = GS * N, QPP = CPW / 4, NCH = GS / 4;  // NCH 16-byte chunks of groups per pixel
     // transpose tile: [64 pixels][NCH chunks] of float4, chunk index XOR-swizzled with the pixel so that both the
@@ -453,12 +501,12 @@ __global__ __launch_bounds__(256) void costvol_fwd_nhwc_kernel(const float *__re
     const bool valid = tile_setup<GS, N, TW, FUSED>(src, K, invK, pose, hyp, prior, ztrans, dm, sg, win, bb, itv, wk, b,
                                                     gbase, p, d0, d1, ox, oy);
     const size_t hw = (size_t)dm.h * dm.w;
-    const float *srcb = src + (size_t)b * dm.C * hw;
+    const io_t *srcb = src + (size_t)b * dm.C * hw;
     vecf<CPW> rf = 0.f;  // ref features with the 1/N of the group mean folded in
     if (valid) {
 #pragma unroll
         for (int k = 0; k < CPW; ++k)
-            rf[k] = ref[((size_t)b * dm.C + Slots<GS, N>::channel(k, dm.G, gbase)) * hw + p] * (1.f / (float)N);
+            rf[k] = ldio(ref + ((size_t)b * dm.C + Slots<GS, N>::channel(k, dm.G, gbase)) * hw + p) * (1.f / (float)N);
     }
     // write-back roles: store k of this lane covers 16-byte piece (k*64 + lane) of the wave's block
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -500,7 +548,7 @@ __global__ __launch_bounds__(256) void costvol_fwd_nhwc_kernel(const float *__re
         for (int k = 0; k < NCH; ++k) {
             const float4 v = my_stage[sidx[k]];
             // (nontemporal stores measured the same, cold output: 76.8 / 77.1 / 76.8 us against 76.7 / 77.1 / 77.3)
-            if (soff[k] >= 0) *reinterpret_cast<float4 *>(out + soff[k] + (long long)(d - d0) * dm.sd) = v;
+            if (soff[k] >= 0) stio4(out + soff[k] + (long long)(d - d0) * dm.sd, v);
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -509,8 +557,8 @@ __global__ __launch_bounds__(256) void costvol_fwd_nhwc_kernel(const float *__re
 }
 
 template <int GS, int N, int TW, bool FUSED>
-__global__ __launch_bounds__(256) void costvol_bwd_kernel(const float *__restrict__ gout, const float *__restrict__ ref,
-                                                          const float *__restrict__ src, const float *__restrict__ K,
+__global__ __launch_bounds__(256) void costvol_bwd_kernel(const io_t *__restrict__ gout, const io_t *__restrict__ ref,
+                                                          const io_t *__restrict__ src, const float *__restrict__ K,
                                                           const float *__restrict__ invK, const float *__restrict__ pose,
                                                           const float *__restrict__ hyp, const float *__restrict__ prior,
                                                           const float *__restrict__ ztrans, float *__restrict__ d_ref,
@@ -534,16 +582,16 @@ __global__ __launch_bounds__(256) void costvol_bwd_kernel(const float *__restric
     const bool valid = tile_setup<GS, N, TW, FUSED>(src, K, invK, pose, hyp, prior, ztrans, dm, sg, win, bb, itv, wk, b,
                                                     gbase, p, d0, d1, ox, oy);  // its barriers publish the zeroed gw
     const size_t hw = (size_t)dm.h * dm.w;
-    const float *srcb = src + (size_t)b * dm.C * hw;
+    const io_t *srcb = src + (size_t)b * dm.C * hw;
     float *dsrcb = d_src + (size_t)b * dm.C * hw;
     if (valid) {
         vecf<CPW> rf, dref = 0.f;
 #pragma unroll
         for (int k = 0; k < CPW; ++k)
-            rf[k] = ref[((size_t)b * dm.C + Slots<GS, N>::channel(k, dm.G, gbase)) * hw + p] * (1.f / (float)N);
+            rf[k] = ldio(ref + ((size_t)b * dm.C + Slots<GS, N>::channel(k, dm.G, gbase)) * hw + p) * (1.f / (float)N);
         vecf<CPW> a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;  // pending d_src quad at cell (bx, by)
         int bx = INT_MIN, by = INT_MIN;
-        const float *gp = gout + (size_t)b * dm.sb + (size_t)gbase * dm.sg + (size_t)d0 * dm.sd + (size_t)p * dm.sp;
+        const io_t *gp = gout + (size_t)b * dm.sb + (size_t)gbase * dm.sg + (size_t)d0 * dm.sd + (size_t)p * dm.sp;
         float dnext = wk.hypothesis(itv, d0);
         for (int d = d0; d <= d1; ++d) {
             Tap4 t;
@@ -553,7 +601,7 @@ __global__ __launch_bounds__(256) void costvol_bwd_kernel(const float *__restric
                 if (d + 1 < d1) dnext = wk.hypothesis(itv, d + 1);
                 float gq[GS];
 #pragma unroll
-                for (int j = 0; j < GS; ++j) gq[j] = gp[(size_t)j * dm.sg];
+                for (int j = 0; j < GS; ++j) gq[j] = ldio(gp + (size_t)j * dm.sg);
                 gp += dm.sd;
                 t = wk.tap_at(dep);
                 const vecf<CPW> S = sample_window<CPW, N, TW>(win, t, ox, oy, srcb, dm.h, dm.w, dm.G, gbase);
@@ -616,8 +664,10 @@ int env_int(const char *name, int dflt) {
 }
 
 struct CvPtrs {
-    const float *gout, *ref, *src, *K, *invK, *pose, *hyp, *prior, *ztrans;
-    float *out, *d_ref, *d_src;
+    const io_t *gout, *ref, *src;
+    const float *K, *invK, *pose, *hyp, *prior, *ztrans;
+    io_t *out;
+    float *d_ref, *d_src;
 };
 
 // Picks (GS, N, TW) and launches.  Supported: N = C/G in {1,2,4,8}, CPW = GS*N in {4,8,16}.
@@ -755,11 +805,13 @@ int check_common(const char *fn, const void *ref, const void *src, const void *K
 
 }  // namespace
 
-extern "C" int md_costvol_fwd(const float *ref, const float *src, const float *K, const float *invK,
+extern "C" int MD_CV_NAME(md_costvol_fwd)(const abi_io_t *ref_, const abi_io_t *src_, const float *K, const float *invK,
                               const float *pose, const float *hyp, const float *prior, const float *ztrans,
-                              float scale_fac, int sched_type, int B, int C, int G, int h, int w, int D, float *out,
+                              float scale_fac, int sched_type, int B, int C, int G, int h, int w, int D, abi_io_t *out_,
                               long long out_sb, long long out_sd, long long out_sg, long long out_sp,
                               md_stream_t stream) {
+    const io_t *ref = reinterpret_cast<const io_t *>(ref_), *src = reinterpret_cast<const io_t *>(src_);
+    io_t *out = reinterpret_cast<io_t *>(out_);
     int rc = check_common("md_costvol_fwd", ref, src, K, invK, pose, hyp, prior, sched_type, B, C, G, h, w, D);
     if (rc) return rc;
     MD_REQUIRE(out, "md_costvol_fwd: null output");
@@ -773,12 +825,14 @@ extern "C" int md_costvol_fwd(const float *ref, const float *src, const float *K
     return launch<false>(q, dm, (hipStream_t)stream);
 }
 
-extern "C" int md_costvol_bwd(const float *gout, long long g_sb, long long g_sd, long long g_sg, long long g_sp,
-                              const float *ref,
-                              const float *src, const float *K, const float *invK, const float *pose,
+extern "C" int MD_CV_NAME(md_costvol_bwd)(const abi_io_t *gout_, long long g_sb, long long g_sd, long long g_sg, long long g_sp,
+                              const abi_io_t *ref_,
+                              const abi_io_t *src_, const float *K, const float *invK, const float *pose,
                               const float *hyp, const float *prior, const float *ztrans, float scale_fac,
                               int sched_type, int B, int C, int G, int h, int w, int D, float *d_ref, float *d_src,
                               md_stream_t stream) {
+    const io_t *gout = reinterpret_cast<const io_t *>(gout_), *ref = reinterpret_cast<const io_t *>(ref_),
+               *src = reinterpret_cast<const io_t *>(src_);
     int rc = check_common("md_costvol_bwd", ref, src, K, invK, pose, hyp, prior, sched_type, B, C, G, h, w, D);
     if (rc) return rc;
     MD_REQUIRE(gout && d_ref && d_src, "md_costvol_bwd: null gradient tensor");

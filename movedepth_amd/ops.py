@@ -87,19 +87,19 @@ def schedule_depth_range(prior_depth, ndepth, scale_fac, z_trans=None, type="inv
 
 
 # --------------------------------------------------------------------------- cost volume
-def _vol_alloc(layout, B, D, G, h, w, device):
+def _vol_alloc(layout, B, D, G, h, w, device, dtype=torch.float32):
     """Storage + (sb, sd, sg, sp) strides + the logical (B,D,G,h,w) view for a grouped volume.
        'bdg'  : (B,D,G,h,w) contiguous -- the reference's layout;
        'bgd'  : (B,G,D,h,w) contiguous -- what reg3d's permute asks for (NCDHW);
        'ndhwc': (B,D,h,w,G) contiguous -- channels_last_3d for reg3d, the layout MIOpen's fast 3-D convs take."""
     if layout == "bgd":
-        store = torch.empty(B, G, D, h, w, device=device, dtype=torch.float32)
+        store = torch.empty(B, G, D, h, w, device=device, dtype=dtype)
         return store, (store.stride(0), store.stride(2), store.stride(1), 1), store.permute(0, 2, 1, 3, 4)
     if layout == "ndhwc":
-        store = torch.empty(B, D, h, w, G, device=device, dtype=torch.float32)
+        store = torch.empty(B, D, h, w, G, device=device, dtype=dtype)
         return store, (store.stride(0), store.stride(1), 1, G), store.permute(0, 1, 4, 2, 3)
     if layout == "bdg":
-        store = torch.empty(B, D, G, h, w, device=device, dtype=torch.float32)
+        store = torch.empty(B, D, G, h, w, device=device, dtype=dtype)
         return store, (store.stride(0), store.stride(1), store.stride(2), 1), store
     raise ValueError("unknown volume layout %r" % (layout,))
 
@@ -124,18 +124,32 @@ def _vol_logical(store, layout):
     return store
 
 
+_HALF_SUFFIX = {torch.bfloat16: "_bf16", torch.float16: "_f16"}
+
+
 class _CostVolume(torch.autograd.Function):
     """Grouped plane-sweep volume; returns a tensor of logical shape (B,D,G,h,w) over `layout` storage."""
 
     @staticmethod
     def forward(ctx, ref, src, K, invK, pose, hyp, prior, ztrans, scale_fac, sched_type, G, D, layout):
-        ref, src = _prep(ref, "ref"), _prep(src, "src")
+        # bf16 / fp16 feature maps (mixed-precision configs): the 2-byte build of the kernel reads them and writes a volume
+        # of the same type; everything else (and any other dtype) is fp32
+        io = ref.dtype if (ref.dtype in _HALF_SUFFIX and src.dtype == ref.dtype) else torch.float32
+        if io == torch.float32:
+            ref, src = _prep(ref, "ref"), _prep(src, "src")
+        else:
+            for t, nm in ((ref, "ref"), (src, "src")):
+                if not t.is_cuda:
+                    raise _lib.MovedepthHipError("%s must be a GPU tensor (got %s)" % (nm, t.device))
+            ref, src = ref.contiguous(), src.contiguous()
+        sfx = _HALF_SUFFIX.get(io, "")
         K, invK, pose = _prep(K, "K"), _prep(invK, "invK"), _prep(pose, "pose")
         hyp, prior, ztrans = _prep(hyp, "depth_priors"), _prep(prior, "prior"), _prep(ztrans, "z_trans")
         B, C, h, w = ref.shape
-        store, (sb, sd, sg, sp), out = _vol_alloc(layout, B, D, G, h, w, ref.device)
-        _timed_call("md_costvol_fwd", _p(ref), _p(src), _p(K), _p(invK), _p(pose), _p(hyp), _p(prior), _p(ztrans),
+        store, (sb, sd, sg, sp), out = _vol_alloc(layout, B, D, G, h, w, ref.device, io)
+        _timed_call("md_costvol_fwd" + sfx, _p(ref), _p(src), _p(K), _p(invK), _p(pose), _p(hyp), _p(prior), _p(ztrans),
                     float(scale_fac), int(sched_type), B, C, G, h, w, D, _p(store), sb, sd, sg, sp, _stream())
+        ctx.sfx, ctx.io = sfx, io
         ctx.save_for_backward(ref, src, K, invK, pose, hyp if hyp is not None else torch.empty(0),
                               prior if prior is not None else torch.empty(0),
                               ztrans if ztrans is not None else torch.empty(0))
@@ -148,12 +162,13 @@ class _CostVolume(torch.autograd.Function):
         ref, src, K, invK, pose, hyp, prior, ztrans = ctx.saved_tensors
         scale_fac, sched_type, G, D, layout, has_hyp, has_prior, has_z = ctx.meta
         B, C, h, w = ref.shape
-        g, (sb, sd, sg, sp) = _vol_as_layout(gout.float(), layout)  # no copy when the consumer kept the layout
-        d_ref, d_src = torch.empty_like(ref), torch.empty_like(src)
-        _timed_call("md_costvol_bwd", _p(g), sb, sd, sg, sp, _p(ref), _p(src), _p(K), _p(invK), _p(pose),
+        g, (sb, sd, sg, sp) = _vol_as_layout(gout.to(ctx.io), layout)  # no copy when the consumer kept the layout
+        d_ref = torch.empty(ref.shape, device=ref.device, dtype=torch.float32)   # fp32 accumulation (atomics)
+        d_src = torch.empty_like(d_ref)
+        _timed_call("md_costvol_bwd" + ctx.sfx, _p(g), sb, sd, sg, sp, _p(ref), _p(src), _p(K), _p(invK), _p(pose),
                     _p(hyp if has_hyp else None), _p(prior if has_prior else None), _p(ztrans if has_z else None),
                     scale_fac, sched_type, B, C, G, h, w, D, _p(d_ref), _p(d_src), _stream())
-        return (d_ref, d_src) + (None,) * 11
+        return (d_ref.to(ctx.io), d_src.to(ctx.io)) + (None,) * 11
 
 
 def costvol_grouped(ref, src, K, invK, pose, G, depth_priors=None, prior=None, ndepth=None, scale_fac=0.3,

@@ -798,3 +798,39 @@ def test_reg3d_fused_bn_paths_agree(ops):
     assert_close(out[0], ref_out[0], what="logits")
     for a, b, what in zip(out[1:], ref_out[1:], ("d_volume", "d_conv0_weight")):
         assert_close(a, b, rtol=5e-3, what=what)   # masks of the fused layers are not hookable: loose bound, see docstring
+
+
+# ------------------------------------------------------------------ cost volume with 2-byte feature maps / volume
+@pytest.mark.parametrize("dtype,tol_rounded,tol_exact", [(torch.bfloat16, 1.5e-3, 4e-3), (torch.float16, 2e-4, 5e-4)])
+@pytest.mark.parametrize("fused,layout", [(False, "bgd"), (True, "bgd"), (True, "ndhwc")])
+@pytest.mark.parametrize("case", [dict(B=2, C=32, G=16, h=24, w=40, D=12), dict(B=1, C=32, G=16, h=48, w=160, D=16)])
+def test_costvol_half_io_vs_oracle(ops, oracle_lib, case, fused, layout, dtype, tol_rounded, tol_exact):
+    """BASELINE configs 4 / 5 precision: bf16 or fp16 feature maps and volume, fp32 arithmetic in between.  The oracle gets
+    the *rounded* features as floats; the kernel's output must equal the oracle's fp32 volume rounded to the format (a
+    result within fp32 noise of a rounding boundary may land on the neighbouring value: norm-wise bound `tol_rounded`,
+    about one format rounding step spread over few elements) and be within the format's own rounding of the exact one."""
+    rng = np.random.default_rng(17)
+    B, C, G, h, w, D = (case[k] for k in "BCGhwD")
+    ref_t = torch.from_numpy(smooth_field(rng, (B, C, h, w), 3, -1, 1)).to(dtype)
+    src_t = torch.from_numpy(smooth_field(rng, (B, C, h, w), 3, -1, 1)).to(dtype)
+    ref, src = ref_t.float().numpy(), src_t.float().numpy()
+    K, invK = kitti_K(h, w, B)
+    prior = (2 + 20 * rng.random((B, 1, h, w))).astype(np.float32)
+    pose = rand_pose(oracle_lib, rng, B, 0.01, 0.05)
+    hyp = oracle_lib.schedule_depth_range(prior, D, 0.3, None, "inverse")
+    gout_t = torch.from_numpy(rng.standard_normal((B, D, G, h, w)).astype(np.float32)).to(dtype)
+    exp = oracle_lib.costvol_grouped(ref, src, K, invK, hyp, pose, G)
+    exp_dref, exp_dsrc = oracle_lib.costvol_grouped_bwd(gout_t.float().numpy(), ref, src, K, invK, hyp, pose)
+    r, s = ref_t.cuda().requires_grad_(True), src_t.cuda().requires_grad_(True)
+    if fused:
+        vol = ops.costvol_grouped(r, s, dev(K), dev(invK), dev(pose), G, prior=dev(prior), ndepth=D, scale_fac=0.3, layout=layout)
+    else:
+        vol = ops.costvol_grouped(r, s, dev(K), dev(invK), dev(pose), G, depth_priors=dev(hyp), layout=layout)
+    assert vol.dtype == dtype and vol.shape == exp.shape
+    got = vol.detach().float().cpu().numpy()
+    assert relerr(got, torch.from_numpy(exp).to(dtype).float().numpy()) <= tol_rounded
+    assert relerr(got, exp) <= tol_exact
+    (vol.float() * gout_t.cuda().float()).sum().backward()
+    assert r.grad.dtype == dtype and s.grad.dtype == dtype
+    assert relerr(r.grad.float().cpu().numpy(), exp_dref) <= tol_exact
+    assert relerr(s.grad.float().cpu().numpy(), exp_dsrc) <= tol_exact

@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--fused", type=int, default=1)
     ap.add_argument("--layout", default="bgd")
     ap.add_argument("--iters", type=int, default=50)
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "f16"], help="feature-map and volume element type")
     ap.add_argument("--rotate", type=int, default=8,
                     help="write into N different output buffers in turn (N x 283 MB >> the 256 MB Infinity Cache), so that a "
                          "launch cannot benefit from lines of its own output left in cache by the previous launch")
@@ -44,8 +45,10 @@ def main():
     dev = "cuda"
     K = torch.tensor([[0.58 * w, 0, 0.5 * w, 0], [0, 1.92 * h, 0.5 * h, 0], [0, 0, 1, 0], [0, 0, 0, 1]], device=dev).repeat(B, 1, 1)
     invK = torch.linalg.pinv(K)
-    ref = torch.randn(B, C, h, w, device=dev, requires_grad=True)
-    src = torch.randn(B, C, h, w, device=dev, requires_grad=True)
+    tdt = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}[a.dtype]
+    eb = 4 if a.dtype == "f32" else 2
+    ref = torch.randn(B, C, h, w, device=dev).to(tdt).requires_grad_(True)
+    src = torch.randn(B, C, h, w, device=dev).to(tdt).requires_grad_(True)
     prior = 2 + 20 * torch.rand(B, 1, h, w, device=dev)
     pose = torch.eye(4, device=dev).repeat(B, 1, 1)
     pose[:, 0, 3], pose[:, 2, 3] = 0.05, 0.03
@@ -71,8 +74,8 @@ def main():
         vol.backward(g, retain_graph=True)
 
     hyp_bytes = 4 * B * h * w if a.fused else 4 * B * D * h * w
-    fbytes = 2 * 4 * B * C * h * w + hyp_bytes + 4 * B * D * G * h * w + 192 * B
-    bbytes = 4 * B * D * G * h * w + 2 * 4 * B * C * h * w + hyp_bytes + 2 * 4 * B * C * h * w
+    fbytes = 2 * eb * B * C * h * w + hyp_bytes + eb * B * D * G * h * w + 192 * B
+    bbytes = eb * B * D * G * h * w + 2 * eb * B * C * h * w + hyp_bytes + 2 * 4 * B * C * h * w
     bigs = [torch.empty_like(vol.contiguous()) for _ in range(max(a.rotate, 1))]
     big = bigs[0]
     zc = [0]
@@ -90,7 +93,7 @@ def main():
     tf = time_fn(fwd, a.iters)
     tb = time_fn(bwd, a.iters)
     env = {k: v for k, v in os.environ.items() if k.startswith("MD_")}
-    print("costvol B=%d %dx%d D=%d C=%d G=%d fused=%d layout=%s env=%s" % (B, h, w, D, C, G, a.fused, a.layout, env))
+    print("costvol B=%d %dx%d D=%d C=%d G=%d fused=%d layout=%s dtype=%s env=%s" % (B, h, w, D, C, G, a.fused, a.layout, a.dtype, env))
     print("  fwd %8.1f us  %7.1f MB  %7.0f GB/s (%.1f%% of 8 TB/s)" % (tf, fbytes / 1e6, fbytes / tf / 1e3, fbytes / tf / 1e3 / 80))
     print("  bwd %8.1f us  %7.1f MB  %7.0f GB/s (%.1f%% of 8 TB/s)  [includes 2 memsets + autograd glue]" % (tb, bbytes / 1e6, bbytes / tb / 1e3, bbytes / tb / 1e3 / 80))
 
