@@ -193,7 +193,7 @@ class _FuseVolumes(torch.autograd.Function):
         B, D, G, h, w = vols[0].shape
         vs, strides = [], None
         for v in vols:
-            st, strides = _vol_as_layout(v, layout)
+            st, strides = _vol_as_layout(v.float(), layout)   # the fusion kernels are fp32 (2-byte volumes are widened here)
             vs.append(st)
         sb, sd, sg, sp = strides
         store = torch.empty_like(vs[0])

@@ -834,3 +834,14 @@ def test_costvol_half_io_vs_oracle(ops, oracle_lib, case, fused, layout, dtype, 
     assert r.grad.dtype == dtype and s.grad.dtype == dtype
     assert relerr(r.grad.float().cpu().numpy(), exp_dref) <= tol_exact
     assert relerr(s.grad.float().cpu().numpy(), exp_dsrc) <= tol_exact
+
+
+def test_fuse_accepts_half_volumes(ops):
+    """Config 5 (three lookup frames, fp16): the fusion kernels are fp32; 2-byte volumes must be widened, not misread."""
+    torch.manual_seed(2)
+    vols32 = [torch.randn(1, 8, 16, 6, 10, device="cuda") for _ in range(3)]
+    vols16 = [v.half() for v in vols32]
+    ref, _ = ops.fuse_volumes([v.half().float() for v in vols32], layout="bdg")
+    got, _ = ops.fuse_volumes(vols16, layout="bdg")
+    assert got.dtype == torch.float32
+    assert_close(host(got), host(ref), rtol=1e-6)
