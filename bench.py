@@ -26,10 +26,11 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (guides/MI355X_MICROARCH.md)
 
 
-def costvol_fwd_bytes(B, C, G, h, w, D, fused):
-    """ref + src features, hypotheses (or the prior when the schedule is fused), grouped volume, K/invK/T."""
+def costvol_fwd_bytes(B, C, G, h, w, D, fused, eb=4):
+    """ref + src features, hypotheses (or the prior when the schedule is fused), grouped volume, K/invK/T;
+    eb = bytes per feature / volume element (4, or 2 under --amp)."""
     hyp = 4 * B * h * w if fused else 4 * B * D * h * w
-    return 2 * 4 * B * C * h * w + hyp + 4 * B * D * G * h * w + 192 * B
+    return 2 * eb * B * C * h * w + hyp + eb * B * D * G * h * w + 192 * B
 
 
 def cpu_baseline(opt):
@@ -152,7 +153,8 @@ def main():
         trainer.train_step(dict(inputs))
     CONV_KERNELS = ["md_conv3d_c16_fwd", "md_conv3d_c16_bwd_data", "md_conv3d_c16_bwd_weight", "md_conv3d_c1_fwd",
                     "md_conv3d_c1_bwd_data", "md_conv3d_c1_bwd_weight"]
-    ops.enable_kernel_timing(["md_costvol_fwd", "md_costvol_bwd"] + CONV_KERNELS)
+    sfx = {"none": "", "bf16": "_bf16", "fp16": "_f16"}[opt.amp]
+    ops.enable_kernel_timing(["md_costvol_fwd" + sfx, "md_costvol_bwd" + sfx] + CONV_KERNELS)
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -169,26 +171,26 @@ def main():
     if rank == 0:
         gb = opt.batch_size * world
         h, w = opt.height // 4, opt.width // 4
-        fbytes = costvol_fwd_bytes(opt.batch_size, 32, opt.reg3d_c, h, w, opt.num_depth_bins, fused=True)
-        kt = times.get("md_costvol_fwd", {})
+        fbytes = costvol_fwd_bytes(opt.batch_size, 32, opt.reg3d_c, h, w, opt.num_depth_bins, fused=True, eb=2 if sfx else 4)
+        kt = times.get("md_costvol_fwd" + sfx, {})
         ach = fbytes / (kt["avg_us"] * 1e-6) / 1e9 if kt else None
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "costvol_fwd_pmc.json")
-        if os.path.exists(pmc):
+        if os.path.exists(pmc) and not sfx:   # the counter file was collected for the fp32 kernel
             traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
         out = {
             "metric": "train-step images/sec at 192x640, D=96; cost-volume HBM GB/s vs roofline",
             "value": gb * a.steps / elapsed, "unit": "images/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": {"none": "f32", "bf16": "bf16", "fp16": "f16"}[opt.amp], "data": "synthetic",
             "config": {"workload": "BASELINE config %d: KITTI 192x640, ResNet18, D=96, batch %d/GPU, fp32, 2-frame cost "
                                    "volume, process_batch+backward+Adam" % (2 if world == 1 else 3, opt.batch_size),
                        "global_batch": gb, "parallelism": "dp%d" % world, "final_loss": loss_val},
-            "roofline": {"bound": "hbm", "kernel": "md_costvol_fwd (plane-sweep cost volume, fused schedule + group mean)",
+            "roofline": {"bound": "hbm", "kernel": "md_costvol_fwd%s (plane-sweep cost volume, fused schedule + group mean)" % sfx,
                          "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (ach / HBM_PEAK_GBS) if ach else None,
                          "traffic": traffic, "algorithmic_bytes_per_launch": fbytes,
                          "avg_launch_us": kt.get("avg_us"), "launches_timed": kt.get("launches"),
-                         "bwd_avg_launch_us": times.get("md_costvol_bwd", {}).get("avg_us")},
+                         "bwd_avg_launch_us": times.get("md_costvol_bwd" + sfx, {}).get("avg_us")},
         }
         # the 3-D regulariser's first / last convolutions (hand-off either side of it), same live HIP-event timing:
         # 16->16 is MFMA-bound (2*27*16*16 flop per voxel against the 157.3 TF/s fp32 MFMA peak), 16->1 is HBM-bound
@@ -210,7 +212,13 @@ def main():
             out["reg3d_handoff_kernels"] = conv
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(opt)
-        print(json.dumps(out))
+        # the library's bf16 / fp16 kernels printf diagnostics to stdout (C stdio, flushed at exit when stdout is a pipe):
+        # push those out first so that the JSON is the last line
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+        if opt.amp != "none":
+            sys.stdout.write("\n")
+        print(json.dumps(out), flush=True)
     if dist.is_available() and dist.is_initialized():
         dist.destroy_process_group()
 

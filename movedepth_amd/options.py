@@ -100,6 +100,9 @@ class MonodepthOptions:
         p.add_argument("--hip_bn_relu", type=int, default=0,
                        help="the 3-D regulariser's two full-resolution BatchNorm+ReLU (+skip add) on the fused kernels.  Off by "
                             "default: measured slower in the step (49.90, 50.04 ms against 49.26, 49.65 ms with the torch ops)")
+        p.add_argument("--amp", default="none", choices=["none", "bf16", "fp16"],
+                       help="mixed precision (BASELINE configs 4 / 5): networks under autocast, 2-byte cost volume; the "
+                            "headline bench is fp32")
         p.add_argument("--fused_adam", type=int, default=1, help="torch's fused Adam kernel on the GPU (0: default implementation)")
         p.add_argument("--sync_bn", type=int, default=1, help="with --ddp: convert BatchNorm to SyncBatchNorm (reference)")
         p.add_argument("--grad_bucket_mb", type=float, default=32.0, help="with --ddp: all-reduce bucket size")

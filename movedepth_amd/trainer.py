@@ -179,15 +179,32 @@ class Trainer:
 
     def train_step(self, inputs):
         """process_batch -> backward -> (gradient all-reduce) -> optimizer step (reference trainer.py:269-272)."""
-        outputs, losses = self.process_batch(inputs, is_train=True)
+        amp = getattr(self.opt, "amp", "none")
+        if amp == "none":
+            outputs, losses = self.process_batch(inputs, is_train=True)
+        else:
+            # BASELINE configs 4 / 5: the networks under autocast (library convolutions on the bf16 / fp16 MFMA paths), the
+            # plane-sweep kernels on their 2-byte builds (they dispatch on the feature dtype); every other hand-written
+            # kernel widens its inputs to fp32, as autocast does for the losses in the reference's ecosystem
+            with torch.autocast("cuda", dtype=torch.bfloat16 if amp == "bf16" else torch.float16):
+                outputs, losses = self.process_batch(inputs, is_train=True)
         if self.grad_sync is not None:
             self.grad_sync.zero_grad()
         else:
             self.model_optimizer.zero_grad(set_to_none=True)
-        losses["loss"].backward()
-        if self.grad_sync is not None:
-            self.grad_sync.finish()
-        self.model_optimizer.step()
+        if amp == "fp16":
+            if getattr(self, "_scaler", None) is None:
+                self._scaler = torch.amp.GradScaler("cuda")
+            self._scaler.scale(losses["loss"]).backward()
+            if self.grad_sync is not None:
+                self.grad_sync.finish()
+            self._scaler.step(self.model_optimizer)
+            self._scaler.update()
+        else:
+            losses["loss"].backward()
+            if self.grad_sync is not None:
+                self.grad_sync.finish()
+            self.model_optimizer.step()
         return outputs, losses
 
     def run_epoch(self):
