@@ -221,6 +221,10 @@ int md_conv3d_c16_bwd_weight(const float *x, int x_planar, const float *gy, floa
  * ws: md_bn_relu_ws_bytes() bytes.  Reductions are two-stage in a fixed order (fp64 final sum). */
 size_t md_bn_relu_ws_bytes(void);
 int md_bn_relu_stats(const float *x, long long nvox, int C, float *sums, void *ws, md_stream_t stream);
+/* mean / invstd from the (all-reduced) sums over n_total voxels; running_mean / running_var (may be NULL) updated in place
+ * with `momentum` (unbiased variance), as F.batch_norm does in training */
+int md_bn_relu_finalize(const float *sums, long long n_total, int C, float eps, float momentum, float *mean, float *invstd,
+                        float *running_mean, float *running_var, md_stream_t stream);
 int md_bn_relu_apply(const float *x, const float *mean, const float *invstd, const float *gamma, const float *beta,
                      const float *res, long long nvox, int C, float *y, md_stream_t stream);
 int md_bn_relu_bwd_reduce(const float *dy, const float *x, const float *mean, const float *invstd, const float *gamma,

@@ -58,6 +58,7 @@ SIGNATURES = {
     "md_conv3d_c16_bwd_weight": (_i, [_vp, _i, _vp, _vp, _ll, _ll, _ll, _vp, _sz, _i, _i, _i, _i, _i, _i, _vp]),
     "md_bn_relu_ws_bytes": (_sz, []),
     "md_bn_relu_stats": (_i, [_vp, _ll, _i, _vp, _vp, _vp]),
+    "md_bn_relu_finalize": (_i, [_vp, _ll, _i, _f, _f, _vp, _vp, _vp, _vp, _vp]),
     "md_bn_relu_apply": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _vp, _vp]),
     "md_bn_relu_bwd_reduce": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _vp, _vp, _vp]),
     "md_bn_relu_bwd_dx": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _ll, _i, _vp, _vp]),

@@ -151,6 +151,25 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const float4 *__restrict
     }
 }
 
+// mean, invstd (biased variance) from the two sums, and BatchNorm's running statistics (unbiased variance), in one tiny
+// launch instead of a dozen host-side tensor ops per call
+__global__ void bn_finalize_kernel(const float *__restrict__ sums, double n, float eps, float momentum, float *__restrict__ mean,
+                                   float *__restrict__ invstd, float *__restrict__ running_mean,
+                                   float *__restrict__ running_var) {
+    const int c = threadIdx.x;
+    if (c >= C) return;
+    const double m = (double)sums[c] / n;
+    double var = (double)sums[C + c] / n - m * m;
+    if (var < 0.0) var = 0.0;
+    mean[c] = (float)m;
+    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) running_mean[c] = running_mean[c] + momentum * ((float)m - running_mean[c]);
+    if (running_var) {
+        const double unb = var * (n / (n > 1.0 ? n - 1.0 : 1.0));
+        running_var[c] = running_var[c] + momentum * ((float)unb - running_var[c]);
+    }
+}
+
 int bn_check(const char *fn, long long nvox, int Cc) {
     MD_REQUIRE(Cc == C, "%s: %d channels unsupported (16 only)", fn, Cc);
     MD_REQUIRE(nvox > 0, "%s: empty volume", fn);
@@ -177,6 +196,16 @@ int md_bn_relu_stats(const float *x, long long nvox, int Cc, float *sums, void *
     MD_CHECK_LAUNCH("md_bn_relu_stats");
     hipLaunchKernelGGL(bn_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float *)ws, nb, sums);
     MD_CHECK_LAUNCH("md_bn_relu_stats(finish)");
+    return MD_OK;
+}
+
+int md_bn_relu_finalize(const float *sums, long long n_total, int Cc, float eps, float momentum, float *mean, float *invstd,
+                        float *running_mean, float *running_var, md_stream_t stream) {
+    MD_REQUIRE(sums && mean && invstd, "md_bn_relu_finalize: null tensor argument");
+    if (int rc = bn_check("md_bn_relu_finalize", n_total, Cc)) return rc;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sums, (double)n_total, eps, momentum, mean,
+                       invstd, running_mean, running_var);
+    MD_CHECK_LAUNCH("md_bn_relu_finalize");
     return MD_OK;
 }
 

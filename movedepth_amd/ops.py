@@ -603,31 +603,29 @@ class _BnRelu3d(torch.autograd.Function):
         C = x.shape[1]
         nvox = x.numel() // C
         ws = _ws(_lib.load().md_bn_relu_ws_bytes(), x.device)
-        sums = torch.empty(2 * C + 1, device=x.device, dtype=torch.float32)
+        sums = torch.empty(2 * C, device=x.device, dtype=torch.float32)
         _timed_call("md_bn_relu_stats", _p(x), nvox, C, _p(sums), _p(ws), _stream())
-        sums[2 * C] = float(nvox)
+        n_total = nvox
         if group is not None:
             dist.all_reduce(sums, group=group)
-        s64 = sums.double()
-        n = s64[2 * C]
-        mean64 = s64[:C] / n
-        var64 = (s64[C:2 * C] / n - mean64 * mean64).clamp_min_(0.0)     # biased, as F.batch_norm in training
-        mean, invstd = mean64.float(), torch.rsqrt(var64 + eps).float()
-        if running_mean is not None:
-            with torch.no_grad():
-                running_mean.lerp_(mean.to(running_mean.dtype), momentum)
-                running_var.lerp_((var64 * (n / (n - 1).clamp_min(1.0))).to(running_var.dtype), momentum)
+            n_total = nvox * dist.get_world_size(group)
+        stat = torch.empty(2 * C, device=x.device, dtype=torch.float32)
+        mean, invstd = stat[:C], stat[C:]
+        rm = running_mean if (running_mean is not None and running_mean.dtype == torch.float32) else None
+        rv = running_var if (running_var is not None and running_var.dtype == torch.float32) else None
+        _lib.call("md_bn_relu_finalize", _p(sums), n_total, C, float(eps), float(momentum), _p(mean), _p(invstd), _p(rm), _p(rv),
+                  _stream())
         y = torch.empty_like(x, memory_format=torch.channels_last_3d)
         w, b = weight.float().contiguous(), bias.float().contiguous()
         _timed_call("md_bn_relu_apply", _p(x), _p(mean), _p(invstd), _p(w), _p(b), _p(res), nvox, C, _p(y), _stream())
-        ctx.save_for_backward(x, mean, invstd, w, b, sums)
+        ctx.save_for_backward(x, mean, invstd, w, b)
         ctx.group, ctx.has_res = group, res is not None
         return y
 
     @staticmethod
     def backward(ctx, dy):
         import torch.distributed as dist
-        x, mean, invstd, w, b, fsums = ctx.saved_tensors
+        x, mean, invstd, w, b = ctx.saved_tensors
         C = x.shape[1]
         nvox = x.numel() // C
         dy = dy.float().contiguous(memory_format=torch.channels_last_3d)
@@ -635,9 +633,11 @@ class _BnRelu3d(torch.autograd.Function):
         sums = torch.empty(2 * C, device=x.device, dtype=torch.float32)
         _timed_call("md_bn_relu_bwd_reduce", _p(dy), _p(x), _p(mean), _p(invstd), _p(w), _p(b), nvox, C, _p(sums), _p(ws),
                     _stream())
-        d_beta, d_gamma = sums[:C].clone(), sums[C:].clone()             # local sums (the gradient reducer averages them)
+        d_beta, d_gamma = sums[:C], sums[C:]                             # local sums (the gradient reducer averages them)
         n_total = nvox
         if ctx.group is not None:
+            local = sums
+            sums = local.clone()
             dist.all_reduce(sums, group=ctx.group)
             n_total = nvox * dist.get_world_size(ctx.group)
         dx = torch.empty_like(x, memory_format=torch.channels_last_3d)
