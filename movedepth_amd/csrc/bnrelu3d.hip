@@ -16,12 +16,13 @@
 
 namespace {
 
-constexpr int C = 16, QN = 4, NBLK = 1024;  // partial sums per launch
+constexpr int NBLK = 1024;  // partial sums per launch; channels C = 4*QN with QN in {4, 8, 16}
 
 __device__ __forceinline__ float4 f4_add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 
-// block-wide sum of per-thread float4 (channels 4q..4q+3 of quad q = tid % 4): result valid in threads 0..3 (one per quad)
-__device__ __forceinline__ float4 quad_block_sum(float4 v, float4 *sh /*[4 waves][4 quads]*/) {
+// block-wide sum of per-thread float4 (channels 4q..4q+3 of quad q = tid % QN): result valid in threads 0..QN-1
+template <int QN>
+__device__ __forceinline__ float4 quad_block_sum(float4 v, float4 *sh /*[4 waves][QN quads]*/) {
 #pragma unroll
     for (int o = QN; o < 64; o <<= 1) {
         v.x += __shfl_xor(v.x, o, 64); v.y += __shfl_xor(v.y, o, 64);
@@ -36,8 +37,9 @@ __device__ __forceinline__ float4 quad_block_sum(float4 v, float4 *sh /*[4 waves
 }
 
 // partial[blk][0][c] = sum x, partial[blk][1][c] = sum x*x over the block's voxels
+template <int QN>
 __global__ __launch_bounds__(256) void bn_stats_kernel(const float4 *__restrict__ x, long long npieces, float *__restrict__ partial) {
-    __shared__ float4 sh[16];
+    __shared__ float4 sh[4 * QN];
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f), ss = s;
     // consecutive threads take consecutive 16-byte pieces; the stride keeps a thread on one channel quad
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < npieces; i += (long long)gridDim.x * 256) {
@@ -45,31 +47,31 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float4 *__restrict_
         s = f4_add(s, v);
         ss.x = fmaf(v.x, v.x, ss.x); ss.y = fmaf(v.y, v.y, ss.y); ss.z = fmaf(v.z, v.z, ss.z); ss.w = fmaf(v.w, v.w, ss.w);
     }
-    s = quad_block_sum(s, sh);
-    ss = quad_block_sum(ss, sh);
+    s = quad_block_sum<QN>(s, sh);
+    ss = quad_block_sum<QN>(ss, sh);
     if (threadIdx.x < QN) {
         reinterpret_cast<float4 *>(partial)[(size_t)blockIdx.x * 2 * QN + threadIdx.x] = s;
         reinterpret_cast<float4 *>(partial)[(size_t)blockIdx.x * 2 * QN + QN + threadIdx.x] = ss;
     }
 }
 
-// sums[k][c] = sum over blocks, fixed order, fp64  (k = 0, 1; 32 outputs)
-__global__ __launch_bounds__(256) void bn_finish_kernel(const float *__restrict__ partial, int nblk, float *__restrict__ sums) {
-    __shared__ double sh[8][32];
-    const int o = threadIdx.x & 31, seg = threadIdx.x >> 5;
+// sums[o] = sum over blocks of partial[blk][o], o < KC = 2*C, fixed order, fp64
+__global__ __launch_bounds__(256) void bn_finish_kernel(const float *__restrict__ partial, int nblk, int KC, float *__restrict__ sums) {
+    __shared__ double sh[256];
+    const int o = threadIdx.x % KC, seg = threadIdx.x / KC, nseg = 256 / KC;
     double s = 0.0;
-    for (int i = seg; i < nblk; i += 8) s += (double)partial[(size_t)i * 32 + o];
-    sh[seg][o] = s;
+    for (int i = seg; i < nblk; i += nseg) s += (double)partial[(size_t)i * KC + o];
+    sh[threadIdx.x] = s;
     __syncthreads();
     if (seg == 0) {
         double t = 0.0;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) t += sh[k][o];
+        for (int k = 0; k < nseg; ++k) t += sh[k * KC + o];
         sums[o] = (float)t;
     }
 }
 
 // scale_c = gamma * invstd, shift_c = beta - mean * scale  ->  y = max(0, x * scale + shift) [+ res]
+template <int QN>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float4 *__restrict__ x, const float *__restrict__ mean,
                                                        const float *__restrict__ invstd, const float *__restrict__ gamma,
                                                        const float *__restrict__ beta, const float4 *__restrict__ res,
@@ -92,11 +94,12 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float4 *__restrict_
 }
 
 // partial[blk][0][c] = sum dz, partial[blk][1][c] = sum dz * xhat
+template <int QN>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float4 *__restrict__ dy, const float4 *__restrict__ x,
                                                             const float *__restrict__ mean, const float *__restrict__ invstd,
                                                             const float *__restrict__ gamma, const float *__restrict__ beta,
                                                             long long npieces, float *__restrict__ partial) {
-    __shared__ float4 sh[16];
+    __shared__ float4 sh[4 * QN];
     const int q = threadIdx.x % QN;
     float mu[4], is[4], ga[4], be[4];
 #pragma unroll
@@ -115,8 +118,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float4 *__rest
         s = f4_add(s, make_float4(a[0], a[1], a[2], a[3]));
         sx = f4_add(sx, make_float4(b[0], b[1], b[2], b[3]));
     }
-    s = quad_block_sum(s, sh);
-    sx = quad_block_sum(sx, sh);
+    s = quad_block_sum<QN>(s, sh);
+    sx = quad_block_sum<QN>(sx, sh);
     if (threadIdx.x < QN) {
         reinterpret_cast<float4 *>(partial)[(size_t)blockIdx.x * 2 * QN + threadIdx.x] = s;
         reinterpret_cast<float4 *>(partial)[(size_t)blockIdx.x * 2 * QN + QN + threadIdx.x] = sx;
@@ -124,6 +127,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float4 *__rest
 }
 
 // dx = gamma * invstd * (dz - sum_dz / n - xhat * sum_dz_xhat / n)
+template <int QN>
 __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const float4 *__restrict__ dy, const float4 *__restrict__ x,
                                                         const float *__restrict__ mean, const float *__restrict__ invstd,
                                                         const float *__restrict__ gamma, const float *__restrict__ beta,
@@ -135,7 +139,7 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const float4 *__restrict
     for (int k = 0; k < 4; ++k) {
         const int c = q * 4 + k;
         mu[k] = mean[c]; is[k] = invstd[c]; ga[k] = gamma[c]; be[k] = beta[c];
-        m1[k] = sums[c] * inv_n; m2[k] = sums[C + c] * inv_n;
+        m1[k] = sums[c] * inv_n; m2[k] = sums[4 * QN + c] * inv_n;
     }
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < npieces; i += (long long)gridDim.x * 256) {
         const float4 v = x[i], g = dy[i];
@@ -153,7 +157,7 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const float4 *__restrict
 
 // mean, invstd (biased variance) from the two sums, and BatchNorm's running statistics (unbiased variance), in one tiny
 // launch instead of a dozen host-side tensor ops per call
-__global__ void bn_finalize_kernel(const float *__restrict__ sums, double n, float eps, float momentum, float *__restrict__ mean,
+__global__ void bn_finalize_kernel(const float *__restrict__ sums, int C, double n, float eps, float momentum, float *__restrict__ mean,
                                    float *__restrict__ invstd, float *__restrict__ running_mean,
                                    float *__restrict__ running_var) {
     const int c = threadIdx.x;
@@ -171,10 +175,17 @@ __global__ void bn_finalize_kernel(const float *__restrict__ sums, double n, flo
 }
 
 int bn_check(const char *fn, long long nvox, int Cc) {
-    MD_REQUIRE(Cc == C, "%s: %d channels unsupported (16 only)", fn, Cc);
+    MD_REQUIRE(Cc == 16 || Cc == 32 || Cc == 64, "%s: %d channels unsupported (16, 32 or 64)", fn, Cc);
     MD_REQUIRE(nvox > 0, "%s: empty volume", fn);
     return MD_OK;
 }
+
+#define MD_BN_DISPATCH(KERNEL, GRID, ...)                                                              \
+    do {                                                                                            \
+        if (QN == 4) hipLaunchKernelGGL(KERNEL<4>, GRID, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__);      \
+        else if (QN == 8) hipLaunchKernelGGL(KERNEL<8>, GRID, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); \
+        else hipLaunchKernelGGL(KERNEL<16>, GRID, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__);             \
+    } while (0)
 
 int bn_blocks(long long npieces) {
     long long n = (npieces + 255) / 256;
@@ -185,16 +196,17 @@ int bn_blocks(long long npieces) {
 
 extern "C" {
 
-size_t md_bn_relu_ws_bytes(void) { return (size_t)NBLK * 2 * C * sizeof(float); }
+size_t md_bn_relu_ws_bytes(void) { return (size_t)NBLK * 2 * 64 * sizeof(float); }
 
 int md_bn_relu_stats(const float *x, long long nvox, int Cc, float *sums, void *ws, md_stream_t stream) {
     MD_REQUIRE(x && sums && ws, "md_bn_relu_stats: null tensor argument");
     if (int rc = bn_check("md_bn_relu_stats", nvox, Cc)) return rc;
+    const int QN = Cc / 4;
     const long long np = nvox * QN;
     const int nb = bn_blocks(np);
-    hipLaunchKernelGGL(bn_stats_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const float4 *)x, np, (float *)ws);
+    MD_BN_DISPATCH(bn_stats_kernel, dim3(nb), (const float4 *)x, np, (float *)ws);
     MD_CHECK_LAUNCH("md_bn_relu_stats");
-    hipLaunchKernelGGL(bn_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float *)ws, nb, sums);
+    hipLaunchKernelGGL(bn_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float *)ws, nb, 2 * Cc, sums);
     MD_CHECK_LAUNCH("md_bn_relu_stats(finish)");
     return MD_OK;
 }
@@ -203,7 +215,7 @@ int md_bn_relu_finalize(const float *sums, long long n_total, int Cc, float eps,
                         float *running_mean, float *running_var, md_stream_t stream) {
     MD_REQUIRE(sums && mean && invstd, "md_bn_relu_finalize: null tensor argument");
     if (int rc = bn_check("md_bn_relu_finalize", n_total, Cc)) return rc;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sums, (double)n_total, eps, momentum, mean,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sums, Cc, (double)n_total, eps, momentum, mean,
                        invstd, running_mean, running_var);
     MD_CHECK_LAUNCH("md_bn_relu_finalize");
     return MD_OK;
@@ -213,11 +225,11 @@ int md_bn_relu_apply(const float *x, const float *mean, const float *invstd, con
                      const float *res, long long nvox, int Cc, float *y, md_stream_t stream) {
     MD_REQUIRE(x && mean && invstd && gamma && beta && y, "md_bn_relu_apply: null tensor argument");
     if (int rc = bn_check("md_bn_relu_apply", nvox, Cc)) return rc;
+    const int QN = Cc / 4;
     const long long np = nvox * QN;
     long long nb = (np + 256 * 4 - 1) / (256 * 4);
     if (nb > 65535 * 16) nb = 65535 * 16;
-    hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (const float4 *)x, mean, invstd, gamma,
-                       beta, (const float4 *)res, np, (float4 *)y);
+    MD_BN_DISPATCH(bn_apply_kernel, dim3((unsigned)nb), (const float4 *)x, mean, invstd, gamma, beta, (const float4 *)res, np, (float4 *)y);
     MD_CHECK_LAUNCH("md_bn_relu_apply");
     return MD_OK;
 }
@@ -226,12 +238,12 @@ int md_bn_relu_bwd_reduce(const float *dy, const float *x, const float *mean, co
                           const float *beta, long long nvox, int Cc, float *sums, void *ws, md_stream_t stream) {
     MD_REQUIRE(dy && x && mean && invstd && gamma && beta && sums && ws, "md_bn_relu_bwd_reduce: null tensor argument");
     if (int rc = bn_check("md_bn_relu_bwd_reduce", nvox, Cc)) return rc;
+    const int QN = Cc / 4;
     const long long np = nvox * QN;
     const int nb = bn_blocks(np);
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const float4 *)dy, (const float4 *)x, mean,
-                       invstd, gamma, beta, np, (float *)ws);
+    MD_BN_DISPATCH(bn_bwd_reduce_kernel, dim3(nb), (const float4 *)dy, (const float4 *)x, mean, invstd, gamma, beta, np, (float *)ws);
     MD_CHECK_LAUNCH("md_bn_relu_bwd_reduce");
-    hipLaunchKernelGGL(bn_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float *)ws, nb, sums);
+    hipLaunchKernelGGL(bn_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float *)ws, nb, 2 * Cc, sums);
     MD_CHECK_LAUNCH("md_bn_relu_bwd_reduce(finish)");
     return MD_OK;
 }
@@ -242,11 +254,11 @@ int md_bn_relu_bwd_dx(const float *dy, const float *x, const float *mean, const 
     MD_REQUIRE(dy && x && mean && invstd && gamma && beta && sums && dx, "md_bn_relu_bwd_dx: null tensor argument");
     if (int rc = bn_check("md_bn_relu_bwd_dx", nvox, Cc)) return rc;
     MD_REQUIRE(n_total >= nvox, "md_bn_relu_bwd_dx: n_total %lld < nvox %lld", n_total, nvox);
+    const int QN = Cc / 4;
     const long long np = nvox * QN;
     long long nb = (np + 256 * 4 - 1) / (256 * 4);
     if (nb > 65535 * 16) nb = 65535 * 16;
-    hipLaunchKernelGGL(bn_bwd_dx_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (const float4 *)dy, (const float4 *)x,
-                       mean, invstd, gamma, beta, sums, 1.f / (float)n_total, np, (float4 *)dx);
+    MD_BN_DISPATCH(bn_bwd_dx_kernel, dim3((unsigned)nb), (const float4 *)dy, (const float4 *)x, mean, invstd, gamma, beta, sums, 1.f / (float)n_total, np, (float4 *)dx);
     MD_CHECK_LAUNCH("md_bn_relu_bwd_dx");
     return MD_OK;
 }

@@ -367,15 +367,26 @@ class reg3d(nn.Module):
             self.conv9 = _up3d(4 * c, 2 * c)
         self.conv11 = _up3d(2 * c, c)
         self.prob = nn.Conv3d(c, 1, 3, stride=1, padding=1, bias=False)
-        # the two full-resolution BatchNorm + ReLU (conv0's, and conv11's together with the skip connection): same
-        # state_dict keys (conv0.bn.*, conv11.1.*), fused kernels on the GPU
-        # fused_bn / --hip_bn_relu: 1.3 ms per step faster than BatchNorm3d + ReLU + add once the statistics are finalised in a
-        # kernel (with a dozen host-side tensor ops per call doing that, it was 0.6 ms slower).
-        self.fused_bn = bool(fused_bn) and c in ops.BN_RELU_CHANNELS
+        # BatchNorm + ReLU (+ the skip add after the three up-convolutions) on the fused kernels wherever the layer has 16, 32
+        # or 64 channels: same state_dict keys (convN.bn.*, convM.1.*).
+        # fused_bn / --hip_bn_relu: 1.3 ms per step faster than BatchNorm3d + ReLU + add on the two full-resolution layers alone
+        # once the statistics are finalised in a kernel (with a dozen host-side tensor ops per call doing that, 0.6 ms slower).
+        self.fused_bn = bool(fused_bn)
+        self.fused_up = {}
         if self.fused_bn:
-            self.conv0.bn = FusedBNReLU3d(c)
-            self.conv11[1] = FusedBNReLU3d(c)
-            self.conv11[2] = nn.Identity()
+            # only the two full-resolution layers: with the half / quarter resolution ones fused too (32 and 64 channels,
+            # 70 and 18 MB tensors) the step got slower again (49.43, 49.52 ms against 47.80, 47.81): five launches per
+            # layer and direction cost more than the passes they save on small tensors
+            for name in ("conv0",):
+                m = getattr(self, name, None)
+                if m is not None and m.bn.num_features in ops.BN_RELU_CHANNELS:
+                    m.bn = FusedBNReLU3d(m.bn.num_features)
+            for name in ("conv11",):
+                m = getattr(self, name, None)
+                if m is not None and m[1].num_features in ops.BN_RELU_CHANNELS:
+                    m[1] = FusedBNReLU3d(m[1].num_features)
+                    m[2] = nn.Identity()
+                    self.fused_up[name] = True
 
     # MIOpen solver search ("find") only for this module's convolutions: without it the fp32 3-D convs fall back to
     # naive kernels (1.67 s fwd+bwd), with it for every conv of the model the first step takes ~18 min of kernel
@@ -401,6 +412,13 @@ class reg3d(nn.Module):
             out.register_hook(lambda g: _set_benchmark(True, g))         # fires before this module's backward
         return out
 
+    def _up(self, name, x, skip):
+        """skip + relu(bn(conv_transpose(x))); with the fused module the add rides in the normalisation pass"""
+        m = getattr(self, name)
+        if self.fused_up.get(name):
+            return m[1](m[0](x), res=skip)
+        return skip + m(x)
+
     def _forward(self, inputs):
         x = inputs.permute(0, 2, 1, 3, 4)  # B,D,G,h,w -> B,G,D,h,w (a view)
         # channels_last_3d (NDHWC) when the module was converted to it: MIOpen's fp32 3-D convolutions are ~75x
@@ -414,7 +432,7 @@ class reg3d(nn.Module):
             if not (x.is_contiguous() or x.is_contiguous(memory_format=torch.channels_last_3d)):
                 x = x.contiguous(memory_format=torch.channels_last_3d)
             c0 = self.conv0.bn(ops.conv3d_16(x, self.conv0.conv.weight, self.lib_conv0_fwd_dgrad))
-            if not self.fused_bn:
+            if not isinstance(self.conv0.bn, FusedBNReLU3d):
                 c0 = F.relu(c0, inplace=True)
         else:
             x = x.contiguous(memory_format=torch.channels_last_3d) if cl else x.contiguous()
@@ -424,14 +442,11 @@ class reg3d(nn.Module):
             c4 = self.conv4(self.conv3(c2))
             x = c4
             if self.down_size >= 3:
-                x = c4 + self.conv7(self.conv6(self.conv5(c4)))
-            x = c2 + self.conv9(x)
+                x = self._up("conv7", self.conv6(self.conv5(c4)), c4)
+            x = self._up("conv9", x, c2)
         else:
             x = c2
-        if self.fused_bn:
-            x = self.conv11[1](self.conv11[0](x), res=c0)   # relu(bn(.)) + c0 in one pass
-        else:
-            x = c0 + self.conv11(x)
+        x = self._up("conv11", x, c0)
         # last layer (C -> 1): hand-written kernels instead of the library's GEMM-shaped ones (1177 / 285 / 2568 us
         # fwd / bwd-data / bwd-weight at 6x16x96x48x160 against ~50 us of memory traffic each); other channel counts
         # and the NCDHW mode stay with the library convolution

@@ -646,7 +646,7 @@ class _BnRelu3d(torch.autograd.Function):
         return dx, d_gamma, d_beta, (dy if ctx.has_res else None), None, None, None, None, None
 
 
-BN_RELU_CHANNELS = (16,)
+BN_RELU_CHANNELS = (16, 32, 64)
 
 
 def bn_relu_3d(x, weight, bias, res=None, running_mean=None, running_var=None, momentum=0.1, eps=1e-5, group=None):
@@ -654,7 +654,7 @@ def bn_relu_3d(x, weight, bias, res=None, running_mean=None, running_var=None, m
     reference networks/resnet_encoder.py:231 (ConvBnReLU3D), :249-252 + :264 (conv11 and the skip connection).
     x (B,16,D,H,W) on the GPU, read as channels_last_3d."""
     if not x.is_cuda or x.shape[1] not in BN_RELU_CHANNELS:
-        raise _lib.MovedepthHipError("bn_relu_3d: needs a GPU tensor with 16 channels, got %s %s" % (x.device, tuple(x.shape)))
+        raise _lib.MovedepthHipError("bn_relu_3d: needs a GPU tensor with 16, 32 or 64 channels, got %s %s" % (x.device, tuple(x.shape)))
     return _BnRelu3d.apply(x.float(), weight, bias, res, running_mean, running_var, float(momentum), float(eps), group)
 
 

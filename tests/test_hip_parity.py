@@ -735,17 +735,19 @@ def test_pose_matrix_matches_torch_form_and_layers_dispatch(ops):
 
 # ------------------------------------------------------------------ fused BatchNorm + ReLU (+ residual), 16 channels
 @pytest.mark.parametrize("shape,with_res", [((2, 16, 5, 7, 9), False), ((2, 16, 5, 7, 9), True), ((1, 16, 1, 1, 3), True),
+                                             ((2, 32, 6, 5, 11), True), ((3, 64, 3, 4, 7), False), ((6, 32, 48, 24, 80), True),
                                              ((6, 16, 96, 48, 160), True)])
 def test_bn_relu_vs_torch(ops, shape, with_res):
     """relu(batch_norm(x)) [+ res] in training mode against the torch ops the reference module uses (BatchNorm3d + ReLU,
     resnet_encoder.py:231 / :249-252, skip add :264): output, all gradients, running statistics.  The last shape is
     BASELINE config 2."""
     torch.manual_seed(13)
+    C = shape[1]
     x = _cl3d(torch.randn(*shape, device="cuda") * 1.5 + 0.3)
     res = _cl3d(torch.randn(*shape, device="cuda")) if with_res else None
-    gamma, beta = torch.rand(16, device="cuda") + 0.5, torch.randn(16, device="cuda") * 0.2
+    gamma, beta = torch.rand(C, device="cuda") + 0.5, torch.randn(C, device="cuda") * 0.2
     gy = _cl3d(torch.randn(*shape, device="cuda"))
-    rm_a, rv_a = torch.zeros(16, device="cuda"), torch.ones(16, device="cuda")
+    rm_a, rv_a = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
     rm_b, rv_b = rm_a.clone(), rv_a.clone()
     xa, ga, ba = x.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
     ra = res.clone().requires_grad_(True) if with_res else None
@@ -760,7 +762,7 @@ def test_bn_relu_vs_torch(ops, shape, with_res):
     if with_res:
         yb = yb + rb
     yb.backward(gy.double())
-    n = x.numel() // 16
+    n = x.numel() // C
     if n > 1:
         assert_close(host(ya), host(yb), what="y")
         assert_close_knife_edge(host(xa.grad), host(xb.grad), rtol=2e-4 if n < 100 else 1e-4, max_outlier_frac=1e-6 if n > 1e5 else 0.0,
