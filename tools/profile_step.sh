@@ -32,6 +32,7 @@ with open("$OUT", "w") as f:
 cat = {"library 3-D conv (CK / naive)": ("ck::", "_ZN2ck", "naive_conv"), "library 2-D conv (Winograd / igemm)": ("miopenSp3AsmConv", "igemm_", "gemm_", "Cijk_"),
        "BatchNorm": ("BatchNorm",), "elementwise / copy / transpose / fill (torch, MIOpen)": ("elementwise", "transpose", "fillBuffer", "SubTensor", "copyBuffer", "CatArray", "reduce_kernel", "upsample", "reflection_pad", "index", "multi_tensor", "fused_adam"),
        "hand-written: cost volume": ("costvol",), "hand-written: reg3d first/last conv": ("conv3d_c",),
+       "hand-written: fused BatchNorm+ReLU": ("bn_",),
        "hand-written: photometric + post-volume": ("warp_", "ssim_", "reproj_", "masked_min", "smooth_", "sel_", "schedule_", "fuse_", "disp_up", "convex", "backproject", "project3d")}
 acc = {k: 0.0 for k in cat}; other = 0.0
 for r in rows:
