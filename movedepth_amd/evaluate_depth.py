@@ -26,18 +26,19 @@ def compute_errors(gt, pred):
 
 
 @torch.no_grad()
-def predict_depth(models, data, opt, vol_layout="ndhwc"):
-    """-> dict(depth_mvs (B,H,W), disp_mono (B,H,W), relative_poses (B,N,4,4)).  `models`: the trainer's dict."""
+def predict_depth(models, data, opt, vol_layout="ndhwc", details=False):
+    """-> dict(depth_mvs (B,H,W), disp_mono (B,H,W), relative_poses (B,N,4,4)).  `models`: the trainer's dict.
+    details=True adds the intermediates the parity tests compare: hyp (B,D,h,w), cor_feats (B,D,G,h,w), cor_weights
+    (one (B,h,w) per lookup frame; empty for a single frame), depth_lowres (B,h,w), disp_prior."""
     dev = next(models["mono_encoder"].parameters()).device
     data = {k: v.to(dev) for k, v in data.items()}
     color = data[("color", 0, 0)]
     output = models["mono_depth"](models["mono_encoder"](color))
-    frames = list(opt.frame_ids)
+    frames = list(opt.matching_ids)   # frames_to_load = opt.matching_ids upstream (evaluate_depth.py:92)
     for fi in frames[1:]:
         pair = [data["color", fi, 0], data["color", 0, 0]] if fi < 0 else [data["color", 0, 0], data["color", fi, 0]]
         axisangle, translation = models["pose"]([models["pose_encoder"](torch.cat(pair, 1))])
         data[("relative_pose", fi)] = transformation_from_parameters(axisangle[:, 0], translation[:, 0], invert=fi < 0)
-    # NB: the reference stacks over frames_to_load[1:] and indexes by matching frame; identical for the defaults
     relative_poses = torch.stack([data[("relative_pose", idx)] for idx in opt.matching_ids[1:]], 1)
     ref_feat, ref_context = models["mvs_encoder"](color)
     src_feats = [models["mvs_encoder"](data["color_aug", f_i, 0])[0] for f_i in opt.matching_ids[1:]]
@@ -50,21 +51,25 @@ def predict_depth(models, data, opt, vol_layout="ndhwc"):
     vols = [ops.costvol_grouped(ref_feat, src_feats[f], data[("K", 2)], data[("inv_K", 2)], relative_poses[:, f],
                                 opt.reg3d_c, prior=depth_prior, ndepth=opt.num_depth_bins, scale_fac=opt.depth_bin_fac,
                                 z_trans=z_trans, type="inverse", layout=vol_layout) for f in range(len(src_feats))]
+    weights = []
     if len(vols) == 1:
         cor = vols[0]  # w/(1e-8 + w): identity to 1.6e-7
     else:
         wsum, cor = 1e-8, 0
         for v in vols:  # evaluation-time confidence: softmax over D of the group mean (evaluate_depth.py:236)
             w = torch.softmax(v.mean(2), dim=1).max(1)[0]
+            weights.append(w)
             wsum = wsum + w
             cor = cor + w.unsqueeze(1).unsqueeze(1) * v
         cor = cor / wsum.unsqueeze(1).unsqueeze(1)
     logits = models["reg3d"](cor)
-    depth_mvs, _, _ = ops.softmax_entropy_localmax(logits, 1 / hyp[:, -1], 1 / hyp[:, 0], opt.norm_radius)
-    if opt.convex_up:
-        depth_mvs = models["up"](depth_mvs, ref_context)
+    depth_low, _, _ = ops.softmax_entropy_localmax(logits, 1 / hyp[:, -1], 1 / hyp[:, 0], opt.norm_radius)
+    depth_mvs = models["up"](depth_low, ref_context) if opt.convex_up else depth_low
     disp_mono, _ = disp_to_depth(output[("disp", 0)], opt.min_depth, opt.max_depth)
-    return {"depth_mvs": depth_mvs, "disp_mono": disp_mono[:, 0], "relative_poses": relative_poses}
+    out = {"depth_mvs": depth_mvs, "disp_mono": disp_mono[:, 0], "relative_poses": relative_poses}
+    if details:
+        out.update(hyp=hyp, cor_feats=cor, cor_weights=weights, depth_lowres=depth_low, disp_prior=disp_prior)
+    return out
 
 
 def evaluate(trainer, loader, gt_fn=None, min_depth=1e-3, max_depth=80.0, median_scaling=True):

@@ -27,6 +27,32 @@ from .layers import (SSIM, BackprojectDepth, Project3D, disp_to_depth, random_im
 from .synthetic import SyntheticLoader
 
 
+def build_models(opt, num_pose_frames=2):
+    """The sub-models of the reference's Trainer.__init__ (trainer.py:67-131), on the CPU, in its construction order.
+    Returns (models, names trained at `learning_rate`, names trained at `learning_rate * lr_fac`)."""
+    models = {}
+    pretrained = opt.weights_init == "pretrained"
+    models["mono_encoder"] = networks.ResnetEncoder(opt.res_arch, pretrained)
+    models["mono_depth"] = networks.DepthDecoder(models["mono_encoder"].num_ch_enc, opt.scales)
+    main = ["mono_encoder", "mono_depth"]
+    if not opt.load_pose:
+        models["pose_encoder"] = networks.ResnetEncoder(opt.res_arch, pretrained, num_input_images=num_pose_frames)
+        models["pose"] = networks.PoseDecoder(models["pose_encoder"].num_ch_enc, num_input_features=1,
+                                              num_frames_to_predict_for=2)
+        main += ["pose_encoder", "pose"]
+    models["mask_cnn"] = networks.UncertNet()
+    models["mvs_encoder"] = networks.FPN4(base_channels=8, scale=opt.prior_scale, dcn=opt.dcn)
+    if opt.num_depth_bins >= 8:
+        models["reg3d"] = networks.reg3d(opt.reg3d_c, opt.reg3d_c, down_size=3, fused_bn=bool(getattr(opt, "hip_bn_relu", 0)))
+    else:
+        models["reg3d"] = networks.reg2d(opt.reg3d_c, opt.reg3d_c)
+    mvs = ["mask_cnn", "mvs_encoder", "reg3d"]
+    if opt.convex_up:
+        models["up"] = networks.convex_upsample_layer(feature_dim=8 * 2 ** opt.prior_scale, scale=opt.prior_scale)
+        main.append("up")
+    return models, main, mvs
+
+
 class Trainer:
     def __init__(self, options):
         self.opt = options
@@ -56,28 +82,8 @@ class Trainer:
         opt = self.opt
 
         # ---- models (names = checkpoint file names of the reference, trainer.py:67-131)
-        self.models = {}
         self.parameters_to_train, self.mvs_parameters_to_train = [], []
-        pretrained = opt.weights_init == "pretrained"
-        self.models["mono_encoder"] = networks.ResnetEncoder(opt.res_arch, pretrained)
-        self.models["mono_depth"] = networks.DepthDecoder(self.models["mono_encoder"].num_ch_enc, opt.scales)
-        main = ["mono_encoder", "mono_depth"]
-        if not opt.load_pose:
-            self.models["pose_encoder"] = networks.ResnetEncoder(opt.res_arch, pretrained,
-                                                                 num_input_images=self.num_pose_frames)
-            self.models["pose"] = networks.PoseDecoder(self.models["pose_encoder"].num_ch_enc, num_input_features=1,
-                                                       num_frames_to_predict_for=2)
-            main += ["pose_encoder", "pose"]
-        self.models["mask_cnn"] = networks.UncertNet()
-        self.models["mvs_encoder"] = networks.FPN4(base_channels=8, scale=opt.prior_scale, dcn=opt.dcn)
-        if opt.num_depth_bins >= 8:
-            self.models["reg3d"] = networks.reg3d(opt.reg3d_c, opt.reg3d_c, down_size=3, fused_bn=bool(opt.hip_bn_relu))
-        else:
-            self.models["reg3d"] = networks.reg2d(opt.reg3d_c, opt.reg3d_c)
-        mvs = ["mask_cnn", "mvs_encoder", "reg3d"]
-        if opt.convex_up:
-            self.models["up"] = networks.convex_upsample_layer(feature_dim=8 * 2 ** opt.prior_scale, scale=opt.prior_scale)
-            main.append("up")
+        self.models, main, mvs = build_models(opt, self.num_pose_frames)
         # library convolutions: the 3-D regulariser runs channels-last (its input volume is written in that layout by
         # the HIP kernel) with MIOpen's solver search enabled for its convs only (see networks.reg3d)
         self.models["reg3d"].find_convs = bool(opt.miopen_find)
@@ -276,14 +282,16 @@ class Trainer:
             logits = self.models["reg3d"](cor_feats)  # B D h w
             return ops.softmax_entropy_localmax(logits, min_inv, max_inv, opt.norm_radius, want_prob=want_prob)
 
-        depth_mvs, cost_prob_entropy, cost_prob = mvs_branch(ref_match_feat, want_prob=opt.mask_mvs_conf)
+        depth_mvs, cost_prob_entropy, _ = mvs_branch(ref_match_feat)
         trust_mono_mask = self.models["mask_cnn"](cost_prob_entropy)  # B 1 h w
 
         # mask-augmented depth prediction
         ori_H, ori_W = inputs["color_aug", 0, 0].shape[2:]
         masked_img, this_aug_mask = random_image_mask(inputs["color_aug", 0, 0], [ori_H // 3, ori_W // 3])
         ref_aug_feat, _ = self.models["mvs_encoder"](masked_img)
-        depth_mvs_aug, _, _ = mvs_branch(ref_aug_feat)
+        # the probability volume behind --mask_mvs_conf is the MASK-AUGMENTED pass's: upstream overwrites `cost_prob` at
+        # trainer.py:394-395 before it is upsampled and thresholded at :414-416
+        depth_mvs_aug, _, cost_prob = mvs_branch(ref_aug_feat, want_prob=opt.mask_mvs_conf)
 
         this_mask = F.interpolate(this_aug_mask, [depth_mvs_aug.shape[1], depth_mvs_aug.shape[2]], mode="bilinear",
                                   align_corners=True).sum(1).to(torch.bool).float()
@@ -465,19 +473,19 @@ class Trainer:
             json.dump(self.opt.__dict__.copy(), f, indent=2)
 
     def save_model(self, save_step=False):
-        """One {model}.pth state_dict per sub-model + adam.pth, rank 0 only (reference trainer.py:807-831)."""
+        """One {model}.pth plain state_dict per sub-model + adam.pth, rank 0 only (reference trainer.py:807-831): the
+        reference evaluator loads each file with strict=True (evaluate_depth.py:118-174), so nothing but the module's own
+        keys may be in it.  Folder: weights_{epoch} (weights_{epoch}_{step} with save_step), 'last' on the final epoch --
+        'last' wins over both, as upstream (:816-817)."""
         if self.rank != 0:
             return
-        name = "weights_{}".format(self.epoch) if self.epoch < self.opt.num_epochs - 1 else "last"
-        if save_step:
-            name = "weights_{}_{}".format(self.epoch, self.step)
+        name = "weights_{}_{}".format(self.epoch, self.step) if save_step else "weights_{}".format(self.epoch)
+        if self.epoch == self.opt.num_epochs - 1:
+            name = "last"
         folder = os.path.join(self.log_path, "models", name)
         os.makedirs(folder, exist_ok=True)
         for model_name, model in self.models.items():
-            sd = model.state_dict()
-            if model_name == "mono_encoder":  # the reference stores the resolution with the encoder
-                sd["height"], sd["width"] = self.opt.height, self.opt.width
-            torch.save(sd, os.path.join(folder, "{}.pth".format(model_name)))
+            torch.save(model.state_dict(), os.path.join(folder, "{}.pth".format(model_name)))
         torch.save(self.model_optimizer.state_dict(), os.path.join(folder, "adam.pth"))
 
     def load_mono_model(self):
@@ -497,9 +505,13 @@ class Trainer:
                 print("Can't load Adam - using random")
 
     def _load_one(self, folder, n):
+        # a misspelt model name or a missing file raises, as upstream (KeyError / FileNotFoundError at trainer.py:861-866):
+        # silently training from random weights is the worse failure
+        if n not in self.models:
+            raise KeyError("--models_to_load: unknown model %r (have %s)" % (n, ", ".join(self.models)))
         path = os.path.join(folder, "{}.pth".format(n))
-        if n not in self.models or not os.path.isfile(path):
-            return
+        if not os.path.isfile(path):
+            raise FileNotFoundError("checkpoint file not found: %s" % path)
         model_dict = self.models[n].state_dict()
         pretrained = torch.load(path, map_location="cpu")
         model_dict.update({k: v for k, v in pretrained.items() if k in model_dict})  # key intersection, as upstream

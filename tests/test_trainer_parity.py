@@ -183,7 +183,11 @@ def test_eval_path_matches_training_forward_and_checkpoint_roundtrip(tmp_path):
     names = sorted(os.listdir(folder))
     assert names == sorted([m + ".pth" for m in t.models] + ["adam.pth"])
     sd = torch.load(os.path.join(folder, "mono_encoder.pth"), map_location="cpu")
-    assert "encoder.conv1.weight" in sd and "encoder.layer4.1.bn2.running_var" in sd and sd["height"] == 64
+    # plain state_dicts, nothing else: the reference evaluator loads them with strict=True (evaluate_depth.py:118-174)
+    for m_name, m in t.models.items():
+        saved = torch.load(os.path.join(folder, m_name + ".pth"), map_location="cpu")
+        assert list(saved.keys()) == list(m.state_dict().keys()), m_name
+    assert "encoder.conv1.weight" in sd and "encoder.layer4.1.bn2.running_var" in sd
     before = {k: v.detach().clone() for k, v in t.models["reg3d"].state_dict().items()}
     with torch.no_grad():
         for p in t.models["reg3d"].parameters():
@@ -192,6 +196,16 @@ def test_eval_path_matches_training_forward_and_checkpoint_roundtrip(tmp_path):
     t.load_model()
     for k, v in t.models["reg3d"].state_dict().items():
         assert torch.equal(v, before[k]), k
+    # 'last' overrides both folder names on the final epoch; a missing file or an unknown model name raises (as upstream)
+    t.epoch = opt.num_epochs - 1
+    t.save_model(save_step=True)
+    assert os.path.isdir(os.path.join(str(tmp_path), "rt", "models", "last"))
+    os.remove(os.path.join(folder, "up.pth"))
+    with pytest.raises(FileNotFoundError):
+        t.load_model()
+    opt.models_to_load = ["pose, reg3d"]   # the reference's malformed default item (options.py:251)
+    with pytest.raises(KeyError):
+        t.load_model()
 
 
 def test_process_batch_three_lookup_frames_and_flags():
