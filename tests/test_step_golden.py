@@ -5,7 +5,8 @@ forward, against fixtures produced by the REFERENCE's own Trainer.process_batch 
 The sub-model weights are rebuilt from a seed on the CPU (tools/step_fixture.py) and proven equal to the generator's by
 per-tensor checksums.  Tolerances: north_star's 1e-4 relative for every loss and for the continuous maps (norm-wise);
 quantities behind a hard decision (the arg-max of a near-uniform probability volume in `localmax`, the auto-mask's
-arg-min, threshold masks) are compared with a small allowance of flipped pixels, stated per assert.
+arg-min, threshold masks) are compared with a small allowance of flipped pixels, stated per assert (measured: none flip).
+Gradients: 1e-4, widened only where the fixture shows the reference's own float32-vs-float64 distance to be larger.
 """
 import os
 import sys
@@ -169,11 +170,14 @@ def test_process_batch_matches_reference(tag):
         report[key] = relerr(host(p.grad), g[key])
     print("[%s] map errs: %s" % (tag, {k: "%.1e" % v for k, v in report.items() if not k.startswith(("loss:", "grad"))}))
     print("[%s] grad errs: %s" % (tag, {k: "%.1e" % v for k, v in report.items() if k.startswith("grad")}))
+    # Gradient bound: 1e-4, or -- where the reference's OWN float32 gradients sit further than that from the same
+    # computation carried in float64 (the fixture's `noise:*` entries, measured by the generator; up to 4e-3 for the MVS
+    # branch at epoch 0, where the hypotheses are close together and the probability volume almost flat) -- 3x that distance:
+    # no float32 implementation can be asked to agree with another more closely than each agrees with the exact result.
     for k, v in report.items():
-        if k.startswith("gradnorm:"):
-            assert v <= 1e-3, (k, v)        # see DESIGN 2: gradients pass through the hard decisions above
-        elif k.startswith("grad:"):
-            assert v <= 2e-3, (k, v)
+        if k.startswith(("gradnorm:", "grad:")):
+            bound = max(1e-4, 3.0 * float(g["noise:" + k]))
+            assert v <= bound, (k, v, bound)
     # BatchNorm running statistics updated with this batch's statistics
     sd = t.models["mvs_encoder"].state_dict()
     assert relerr(host(sd["conv0.0.bn.running_mean"]), g["bn:mvs_encoder.conv0.0.bn.running_mean"]) <= 1e-4

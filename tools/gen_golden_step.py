@@ -92,18 +92,48 @@ def parse_ref_options(extra):
         sys.argv = argv
 
 
-def run_case(tag, epoch, extra, L, Trainer, networks, frames):
+FULL_GRADS = (("mask_cnn", "head_convs.weight"), ("mask_cnn", "conv1.0.weight"), ("up", "upsample_mask.2.weight"),
+              ("pose", "net.3.weight"), ("pose", "net.3.bias"), ("reg3d", "prob.weight"), ("reg3d", "conv0.conv.weight"),
+              ("mvs_encoder", "out.weight"), ("mono_depth", "decoder.10.conv.weight"),
+              ("mono_encoder", "encoder.conv1.weight"), ("pose_encoder", "encoder.conv1.weight"))
+
+
+def _run_reference(epoch, extra, L, Trainer, networks, frames, dtype):
+    """One reference process_batch + backward in `dtype`.  float64 is the reference's own arithmetic carried in double
+    (same seeds, the float32 tie-break noise widened) -- used only to measure how far its float32 gradients sit from
+    the exact ones, which bounds what any other float32 implementation can be asked to reproduce."""
     _, models = build_weights(extra)
     ref_opt = parse_ref_options(extra)
-    t = ref_trainer(L, Trainer, networks, ref_opt, models)
-    t.epoch = epoch
-    inputs = {k: v.clone() for k, v in frames.items()}
-    torch.manual_seed(STEP_SEED)
-    np.random.seed(STEP_SEED)
-    with warnings.catch_warnings():
-        warnings.simplefilter("ignore")
-        outputs, losses = t.process_batch(inputs, is_train=True)
-        losses["loss"].backward()
+    prev, orig_randn = torch.get_default_dtype(), torch.randn
+    torch.set_default_dtype(dtype)
+    try:
+        t = ref_trainer(L, Trainer, networks, ref_opt, models)
+        t.epoch = epoch
+        if dtype == torch.float64:
+            torch.randn = lambda *a, **k: orig_randn(*a, dtype=torch.float32, **k).double()
+            for m in list(t.models.values()) + [t.backprojector, t.projector, t.ssim] + list(t.backproject_depth.values()) + \
+                    list(t.project_3d.values()):
+                m.double()
+        inputs = {k: v.clone().to(dtype) for k, v in frames.items()}
+        torch.manual_seed(STEP_SEED)
+        np.random.seed(STEP_SEED)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            outputs, losses = t.process_batch(inputs, is_train=True)
+            losses["loss"].backward()
+    finally:
+        torch.set_default_dtype(prev)
+        torch.randn = orig_randn
+    return t, inputs, outputs, losses
+
+
+def _rel(a, b):
+    return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-300))
+
+
+def run_case(tag, epoch, extra, L, Trainer, networks, frames):
+    t, inputs, outputs, losses = _run_reference(epoch, extra, L, Trainer, networks, frames, torch.float32)
+    t64, _, _, _ = _run_reference(epoch, extra, L, Trainer, networks, frames, torch.float64)
     d = {"epoch": epoch, "flags": " ".join(extra), "step_seed": STEP_SEED, "weight_seed": WEIGHT_SEED}
     for k, v in losses.items():
         d["loss:" + k] = v
@@ -134,17 +164,19 @@ def run_case(tag, epoch, extra, L, Trainer, networks, frames):
         for pn, p in t.models[name].named_parameters():
             norms.append(0.0 if p.grad is None else float(p.grad.double().norm()))
         d["gradnorm:" + name] = np.array(norms, np.float64)
-    for name, pn in (("mask_cnn", "head_convs.weight"), ("mask_cnn", "conv1.0.weight"), ("up", "upsample_mask.2.weight"),
-                     ("pose", "net.3.weight"), ("pose", "net.3.bias"), ("reg3d", "prob.weight"),
-                     ("reg3d", "conv0.conv.weight"), ("mvs_encoder", "out.weight"), ("mono_depth", "decoder.10.conv.weight"),
-                     ("mono_encoder", "encoder.conv1.weight"), ("pose_encoder", "encoder.conv1.weight")):
+    for name, pn in FULL_GRADS:
         p = dict(t.models[name].named_parameters())[pn]
         d["grad:%s:%s" % (name, pn)] = p.grad
+        d["noise:grad:%s:%s" % (name, pn)] = _rel(p.grad, dict(t64.models[name].named_parameters())[pn].grad)
+    # the reference's own float32-vs-float64 distance for every sub-model's vector of per-parameter gradient norms
+    for name in sorted(t.models):
+        n32 = torch.tensor([0.0 if p.grad is None else float(p.grad.double().norm()) for _, p in t.models[name].named_parameters()])
+        n64 = torch.tensor([0.0 if p.grad is None else float(p.grad.double().norm()) for _, p in t64.models[name].named_parameters()])
+        d["noise:gradnorm:" + name] = _rel(n32, n64)
     # BatchNorm running statistics after the step (momentum update with the batch statistics)
     d["bn:mvs_encoder.conv0.0.bn.running_mean"] = t.models["mvs_encoder"].state_dict()["conv0.0.bn.running_mean"]
     d["bn:reg3d.conv0.bn.running_var"] = t.models["reg3d"].state_dict()["conv0.bn.running_var"]
     save("step_" + tag, d)
-    return models
 
 
 def gen_eval(L, networks, frames):
@@ -241,9 +273,8 @@ def main():
     for s in range(4):
         fx["K_%d" % s], fx["inv_K_%d" % s] = frames[("K", s)], frames[("inv_K", s)]
     fx["dims"] = np.array([B, H, W, D])
-    models = None
     for tag, (epoch, extra) in CASES.items():
-        models = run_case(tag, epoch, extra, L, Trainer, networks, frames)
+        run_case(tag, epoch, extra, L, Trainer, networks, frames)
     _, fresh = build_weights()
     for name, cs in checksums(fresh).items():
         fx["wsum:" + name] = cs
