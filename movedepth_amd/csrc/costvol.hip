@@ -94,6 +94,7 @@ struct CvDims {
     int B, C, G, h, w, D;
     int tiles_x, tiles, splits;  // pixel tiles per sample (x, total) and channel splits
     int items;                   // B * tiles * splits work items of D hypotheses each
+    int dbg;                     // tuning only (MD_CV_DBG): bit 0 skip LDS atomics, 1 skip window flush, 2 skip gradient loads
     long long sb, sd, sg, sp;
 };
 
@@ -163,6 +164,23 @@ struct Walk {
     __device__ __forceinline__ float hypothesis(const float *itv, int k) const {
         if (!FUSED) return hyp_p[(size_t)k * hyp_stride];
         return md_hyp_eval(hc, itv[k - d0], sched_type);
+    }
+    // tap range allowing for rounding of the position (see ClWalk::tap_range in costvol_cl.inc)
+    __device__ __forceinline__ void tap_range(float dep, int &x_lo, int &x_hi, int &y_lo, int &y_hi) const {
+        float ix, iy;
+        if (kReferenceOpOrder) {
+            md_project_fast(cam, r0, r1, r2, dep, wm1, hm1, rw, rh, ix, iy);
+        } else {
+            const float rz = md_rcp_nr(fmaf(dep, A2, B2));
+            ix = fmaf(dep, A0, B0) * rz;
+            iy = fmaf(dep, A1, B1) * rz;
+        }
+        const float ex = 1e-3f + 4e-6f * fabsf(ix), ey = 1e-3f + 4e-6f * fabsf(iy);
+        const bool ok = ix == ix && iy == iy;
+        x_lo = ok ? (int)fminf(fmaxf(floorf(ix - ex), -1e9f), 1e9f) : INT_MAX;
+        x_hi = ok ? (int)fminf(fmaxf(floorf(ix + ex), -1e9f), 1e9f) : INT_MIN;
+        y_lo = ok ? (int)fminf(fmaxf(floorf(iy - ey), -1e9f), 1e9f) : INT_MAX;
+        y_hi = ok ? (int)fminf(fmaxf(floorf(iy + ey), -1e9f), 1e9f) : INT_MIN;
     }
     __device__ __forceinline__ Tap4 tap_at(float dep) const {
         float ix, iy;
@@ -364,10 +382,13 @@ __device__ __forceinline__ bool tile_setup(const io_t *__restrict__ src, const f
     if (valid && d1 > d0) {
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-            const Tap4 t = wk.tap_at(wk.hypothesis(itv, e ? d1 - 1 : d0));
-            if (t.x0 >= -1 && t.x0 < dm.w && t.y0 >= -1 && t.y0 < dm.h) {
-                mnx = min(mnx, t.x0); mxx = max(mxx, t.x0 + 1);
-                mny = min(mny, t.y0); mxy = max(mxy, t.y0 + 1);
+            // (allowing for rounding: a coordinate sitting on an integer -- static camera -- lands on either side of it from
+            // step to step; bounding by the end points' taps alone sent such rows down the global-memory path: 3-7x slower)
+            int xl, xh, yl, yh;
+            wk.tap_range(wk.hypothesis(itv, e ? d1 - 1 : d0), xl, xh, yl, yh);
+            if (xh >= -1 && xl < dm.w && yh >= -1 && yl < dm.h) {
+                mnx = min(mnx, max(xl, -1)); mxx = max(mxx, min(xh, dm.w - 1) + 1);
+                mny = min(mny, max(yl, -1)); mxy = max(mxy, min(yh, dm.h - 1) + 1);
             }
         }
     }
@@ -670,9 +691,68 @@ struct CvPtrs {
     float *d_ref, *d_src;
 };
 
-// Picks (GS, N, TW) and launches.  Supported: N = C/G in {1,2,4,8}, CPW = GS*N in {4,8,16}.
+#include "costvol_cl.inc"
+
+// Launch of the channels-last kernels (costvol_cl.inc).  Grid = the chip's resident workgroup slots for the kernel
+// (occupancy query), each workgroup taking an equal contiguous share of the items x D hypothesis steps.
+template <bool BWD, int N, int LPP, int NW, bool FUSED>
+int launch_cl_inst(const CvPtrs &q, const CvDims &dm, hipStream_t stream) {
+    const void *fn = BWD ? (const void *)cl_bwd_kernel<N, LPP, NW, FUSED> : (const void *)cl_fwd_kernel<N, LPP, NW, FUSED>;
+    const long long total = (long long)dm.items * dm.D;
+    long long nwg = env_int(BWD ? "MD_COSTVOL_NWG_BWD" : "MD_COSTVOL_NWG", 0);
+    if (nwg <= 0) {
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64 * NW, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        nwg = (long long)cus * per_cu;
+    }
+    if (nwg > total) nwg = total;
+    if (nwg * ITV_MAX < total) nwg = (total + ITV_MAX - 1) / ITV_MAX;  // a share fits the interval table
+    const dim3 grid((unsigned)nwg), block(64 * NW);
+    if (BWD)
+        hipLaunchKernelGGL((cl_bwd_kernel<N, LPP, NW, FUSED>), grid, block, 0, stream, q.gout, q.ref, q.src, q.K, q.invK,
+                           q.pose, q.hyp, q.prior, q.ztrans, q.d_ref, q.d_src, dm);
+    else
+        hipLaunchKernelGGL((cl_fwd_kernel<N, LPP, NW, FUSED>), grid, block, 0, stream, q.ref, q.src, q.K, q.invK, q.pose,
+                           q.hyp, q.prior, q.ztrans, q.out, dm);
+    MD_CHECK_LAUNCH(BWD ? "md_costvol_bwd (channels-last)" : "md_costvol_fwd (channels-last)");
+    return MD_OK;
+}
+
+template <bool BWD>
+int launch_cl(const CvPtrs &q, CvDims dm, hipStream_t stream) {
+    const int N = dm.C / dm.G, LPP = dm.G / 4, TW = 64 / LPP;
+    const int NW = env_int(BWD ? "MD_COSTVOL_CL_NW_BWD" : "MD_COSTVOL_CL_NW", 8) == 4 ? 4 : 8;
+    dm.tiles_x = md_cdiv(dm.w, TW);
+    dm.tiles = dm.tiles_x * md_cdiv(dm.h, NW);
+    dm.splits = 1;
+    dm.items = dm.B * dm.tiles;
+    dm.dbg = env_int("MD_CV_DBG", 0);
+#define MD_CL_F(N_, LPP_)                                                                                        \
+    do {                                                                                                         \
+        if (NW == 4)                                                                                             \
+            return q.hyp ? launch_cl_inst<BWD, N_, LPP_, 4, false>(q, dm, stream)                                \
+                         : launch_cl_inst<BWD, N_, LPP_, 4, true>(q, dm, stream);                                \
+        return q.hyp ? launch_cl_inst<BWD, N_, LPP_, 8, false>(q, dm, stream)                                    \
+                     : launch_cl_inst<BWD, N_, LPP_, 8, true>(q, dm, stream);                                    \
+    } while (0)
+    switch (N * 10 + LPP) {
+        case 14: MD_CL_F(1, 4);
+        case 24: MD_CL_F(2, 4);
+        case 44: MD_CL_F(4, 4);
+        case 12: MD_CL_F(1, 2);
+        case 22: MD_CL_F(2, 2);
+        case 42: MD_CL_F(4, 2);
+    }
+#undef MD_CL_F
+    md_set_error("costvol: no channels-last kernel for C=%d G=%d", dm.C, dm.G);
+    return MD_EINVAL;
+}
+
 template <bool BWD>
 int launch(const CvPtrs &q, CvDims dm, hipStream_t stream) {
+    if (cl_eligible(dm, BWD ? (const void *)q.gout : (const void *)q.out)) return launch_cl<BWD>(q, dm, stream);
     const int N = dm.C / dm.G;
     if (N != 1 && N != 2 && N != 4 && N != 8) {
         md_set_error("costvol: unsupported channel grouping C=%d G=%d (C/G must be 1, 2, 4 or 8)", dm.C, dm.G);

@@ -48,6 +48,11 @@ def _trainer(extra, tmp_path=None):
     from movedepth_amd.trainer import Trainer
 
     opt = MovedepthOptions().parse(fx.BASE_ARGS + list(extra) + ["--automask_noise", "host", "--miopen_find", "0"])
+    # library convolutions: no solver search, deterministic solvers only.  Which weight-gradient solver MIOpen picks for the
+    # small 2-D convolutions otherwise depends on what ran earlier in the process, and one of them is only good to ~1e-3
+    # (mvs_encoder.conv0.0 weight gradient 8e-4 off in one process, 3e-6 in another, same inputs).
+    torch.backends.cudnn.benchmark = False
+    torch.backends.cudnn.deterministic = True
     t = Trainer(opt)
     _, cpu_models = fx.build_weights(extra)
     for k, m in t.models.items():
@@ -134,16 +139,16 @@ def test_process_batch_matches_reference(tag):
     assert report["color_m1_0"] <= 1e-4
     # maps downstream of localmax's arg-max over a near-uniform probability volume (untrained weights: neighbouring
     # bins differ by ~1e-3 relative): a pixel whose arg-max moves to the neighbouring bin changes its depth by a few
-    # per cent; allow 1 % of such pixels, the rest must agree to 1e-4
+    # per cent; allow 0.2 % of such pixels (none observed), the rest must agree to 1e-4
     for key in ("depth_mvs", "masked_depth", "fused_depth", "mvs_reprojection_loss"):
-        r, frac = _flip_tolerant(host(outputs[key]), g["out:" + key], key, rtol=1e-4, max_flip_frac=1e-2)
+        r, frac = _flip_tolerant(host(outputs[key]), g["out:" + key], key, rtol=1e-4, max_flip_frac=2e-3)
         report[key], report[key + ":flips"] = r, frac
     for n, f in (("m1", -1), ("p1", 1)):
-        r, frac = _flip_tolerant(host(outputs[("mvs_color", f)]), g["out:mvs_color_" + n], "mvs_color", 1e-4, 1e-2)
+        r, frac = _flip_tolerant(host(outputs[("mvs_color", f)]), g["out:mvs_color_" + n], "mvs_color", 1e-4, 2e-3)
         report["mvs_color_" + n] = r
         flips = float((host(outputs[("mvs_mask", f)]).astype(bool) != g["out:mvs_mask_" + n]).mean())
         assert flips <= 2e-3, ("mvs_mask", n, flips)
-    r, frac = _flip_tolerant(host(outputs[("mvs_color_fuse", 1)]), g["out:mvs_color_fuse_p1"], "mvs_color_fuse", 1e-4, 1e-2)
+    r, frac = _flip_tolerant(host(outputs[("mvs_color_fuse", 1)]), g["out:mvs_color_fuse_p1"], "mvs_color_fuse", 1e-4, 2e-3)
     assert abs(float(outputs["mvs_reproj_loss"]) - float(g["out:mvs_reproj_loss"])) <= 1e-4 * float(g["out:mvs_reproj_loss"])
     # boolean / 0-1 masks: fraction of differing pixels
     flips = float((host(outputs["reprojection_loss_mask"]) != g["out:reprojection_loss_mask"]).mean())
@@ -162,6 +167,9 @@ def test_process_batch_matches_reference(tag):
         assert got.shape == want.shape, name
         # compare the vector of norms norm-wise, and each sizeable entry individually
         report["gradnorm:" + name] = relerr(got, want)
+        names = [pn for pn, _ in m.named_parameters()]
+        worst = np.argsort(-np.abs(got - want))[:4]
+        print("[%s] %s worst |d norm|: %s" % (tag, name, [(names[i], "%.3e" % want[i], "%.1e" % (abs(got[i] - want[i]) / (want[i] + 1e-30))) for i in worst]))
         big = want > 1e-3 * want.max()
         report["gradnorm_max:" + name] = float(np.max(np.abs(got[big] - want[big]) / want[big]))
     for key in [k for k in g if k.startswith("grad:")]:
@@ -207,6 +215,6 @@ def test_eval_forward_matches_reference(tag, matching):
     r = relerr(host(out["cor_feats"]), g["cor_feats"])
     print("\n[eval %s] cor_feats %.1e" % (tag, r))
     assert r <= 1e-4
-    r1, f1 = _flip_tolerant(host(out["depth_lowres"]), g["depth_lowres"], "depth_lowres", 1e-4, 1e-2)
-    r2, f2 = _flip_tolerant(host(out["depth_mvs"]), g["pred_depth"], "pred_depth", 1e-4, 1e-2)
+    r1, f1 = _flip_tolerant(host(out["depth_lowres"]), g["depth_lowres"], "depth_lowres", 1e-4, 2e-3)
+    r2, f2 = _flip_tolerant(host(out["depth_mvs"]), g["pred_depth"], "pred_depth", 1e-4, 2e-3)
     print("[eval %s] depth_lowres %.1e (flips %.1e), pred_depth %.1e (flips %.1e)" % (tag, r1, f1, r2, f2))

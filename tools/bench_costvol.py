@@ -36,6 +36,9 @@ def main():
     ap.add_argument("--layout", default="bgd")
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "f16"], help="feature-map and volume element type")
+    ap.add_argument("--prior", default=os.environ.get("PRIOR", "white"), choices=["white", "smooth", "const"],
+                    help="depth prior: white noise per pixel in [2,22) (adversarial: neighbouring pixels sweep unrelated epipolar "
+                         "segments), a smooth field (what the mono decoder produces), or a constant")
     ap.add_argument("--rotate", type=int, default=8,
                     help="write into N different output buffers in turn (N x 283 MB >> the 256 MB Infinity Cache), so that a "
                          "launch cannot benefit from lines of its own output left in cache by the previous launch")
@@ -49,9 +52,15 @@ def main():
     eb = 4 if a.dtype == "f32" else 2
     ref = torch.randn(B, C, h, w, device=dev).to(tdt).requires_grad_(True)
     src = torch.randn(B, C, h, w, device=dev).to(tdt).requires_grad_(True)
-    prior = 2 + 20 * torch.rand(B, 1, h, w, device=dev)
+    if a.prior == "white":
+        prior = 2 + 20 * torch.rand(B, 1, h, w, device=dev)
+    elif a.prior == "smooth":
+        coarse = torch.rand(B, 1, max(2, h // 12), max(2, w // 12), device=dev)
+        prior = 2 + 20 * torch.nn.functional.interpolate(coarse, size=(h, w), mode="bilinear", align_corners=True)
+    else:
+        prior = torch.full((B, 1, h, w), float(os.environ.get("PRIOR_CONST", "8.0")), device=dev)
     pose = torch.eye(4, device=dev).repeat(B, 1, 1)
-    pose[:, 0, 3], pose[:, 2, 3] = 0.05, 0.03
+    pose[:, 0, 3], pose[:, 2, 3] = float(os.environ.get("POSE_TX", "0.05")), float(os.environ.get("POSE_TZ", "0.03"))
     hyp = ops.schedule_depth_range(prior, D, 0.3)
     kw = dict(prior=prior, ndepth=D, scale_fac=0.3) if a.fused else dict(depth_priors=hyp)
     vol = ops.costvol_grouped(ref, src, K, invK, pose, G, layout=a.layout, **kw)
@@ -93,7 +102,7 @@ def main():
     tf = time_fn(fwd, a.iters)
     tb = time_fn(bwd, a.iters)
     env = {k: v for k, v in os.environ.items() if k.startswith("MD_")}
-    print("costvol B=%d %dx%d D=%d C=%d G=%d fused=%d layout=%s dtype=%s env=%s" % (B, h, w, D, C, G, a.fused, a.layout, a.dtype, env))
+    print("costvol B=%d %dx%d D=%d C=%d G=%d fused=%d layout=%s dtype=%s prior=%s env=%s" % (B, h, w, D, C, G, a.fused, a.layout, a.dtype, a.prior, env))
     print("  fwd %8.1f us  %7.1f MB  %7.0f GB/s (%.1f%% of 8 TB/s)" % (tf, fbytes / 1e6, fbytes / tf / 1e3, fbytes / tf / 1e3 / 80))
     print("  bwd %8.1f us  %7.1f MB  %7.0f GB/s (%.1f%% of 8 TB/s)  [includes 2 memsets + autograd glue]" % (tb, bbytes / 1e6, bbytes / tb / 1e3, bbytes / tb / 1e3 / 80))
 

@@ -12,8 +12,8 @@ constexpr int B = 6, D = 96, G = 16, H = 48, W = 160, TW = 32, TH = 8;
 constexpr int TILES_X = W / TW, TILES = TILES_X * (H / TH), ITEMS = B * TILES;
 
 // LAYOUT 0: (B,D,h,w,G) channels-last;  1: tile-blocked (B,tile,D,256 px,G): a workgroup's steps are one contiguous stream
-template <int LAYOUT>
-__global__ __launch_bounds__(256) void probe(float *__restrict__ out, const float *__restrict__ src, int nfma, int nlds) {
+template <int LAYOUT, bool NOLDS = false, int WAITN = -1>
+__global__ __launch_bounds__(256) void probe(float *__restrict__ out, const float *__restrict__ src, int nfma, int nlds, int kslices = 0) {
     extern __shared__ float4 smem[];  // [0, 1024): transpose tiles (4 waves x 64 px x 4 chunks); the rest: dummy window
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float4 *my_stage = smem + wave * 256;
@@ -22,10 +22,17 @@ __global__ __launch_bounds__(256) void probe(float *__restrict__ out, const floa
     __syncthreads();
     const long long total = (long long)ITEMS * D;
     long long lo = total * blockIdx.x / gridDim.x;
-    const long long hi = total * (blockIdx.x + 1) / gridDim.x;
+    long long hi = total * (blockIdx.x + 1) / gridDim.x;
+    if (kslices > 0) {
+        // item-aligned: workgroup = (slice, item), consecutive workgroups = consecutive tiles at the same d range, so the
+        // whole grid sweeps d in lockstep (kslices moving windows of 6 planes each)
+        const int item = blockIdx.x % ITEMS, sl = blockIdx.x / ITEMS;
+        lo = (long long)item * D + (long long)D * sl / kslices;
+        hi = (long long)item * D + (long long)D * (sl + 1) / kslices;
+    }
     float og[16];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) og[j] = (float)(tid + j);
+    for (int j = 0; j < 16; ++j) og[j] = kslices < 0 ? 1.f : (float)(tid + j);
     const float a = src[tid & 15], c = src[16 + (tid & 15)];
     while (lo < hi) {
         const int item = (int)(lo / D), d0 = (int)(lo % D);
@@ -59,6 +66,12 @@ __global__ __launch_bounds__(256) void probe(float *__restrict__ out, const floa
                 for (int j = 0; j < 16; ++j) og[j] = fmaf(og[j], a, c);
             }
             og[0] += acc.x; og[1] += acc.y; og[2] += acc.z; og[3] += acc.w;
+            if (NOLDS) {
+                // same addresses, values straight from registers (wrong values: this only prices the LDS transpose)
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    *reinterpret_cast<float4 *>(out + soff[k] + (long long)(d - d0) * sd) = make_float4(og[4 * k], og[4 * k + 1], og[4 * k + 2], og[4 * k + 3]);
+            } else {
 #pragma unroll
             for (int cidx = 0; cidx < 4; ++cidx)
                 my_stage[lane * 4 + (cidx ^ ((lane >> 1) & 3))] = make_float4(og[4 * cidx], og[4 * cidx + 1], og[4 * cidx + 2], og[4 * cidx + 3]);
@@ -69,9 +82,29 @@ __global__ __launch_bounds__(256) void probe(float *__restrict__ out, const floa
                 *reinterpret_cast<float4 *>(out + soff[k] + (long long)(d - d0) * sd) = v;
             }
             __builtin_amdgcn_wave_barrier();
+            }
+            // flow control: let at most WAITN of this wave's stores stay in flight before it goes on
+            if (WAITN == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (WAITN == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            if (WAITN == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            if (WAITN == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            if (WAITN == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         }
         lo += d1 - d0;
     }
+}
+
+// every block writes one contiguous chunk of `per` float4 per thread-row (what an elementwise library kernel does)
+__global__ __launch_bounds__(256) void fill_chunked(float4 *out, size_t n4, int per, int varied = 0) {
+    size_t base = (size_t)blockIdx.x * 256 * per + threadIdx.x;
+    float4 v = make_float4(1.f, 2.f, 3.f, 4.f);
+    if (varied) {  // pseudo-random bit patterns per element (hash of the index), as real data would be
+        unsigned h = (unsigned)base * 2654435761u;
+        v = make_float4(__uint_as_float((h & 0x007fffffu) | 0x3f000000u), __uint_as_float(((h * 31u) & 0x007fffffu) | 0x3f000000u),
+                        __uint_as_float(((h * 131u) & 0x007fffffu) | 0x3f000000u), __uint_as_float(((h * 1031u) & 0x007fffffu) | 0x3f000000u));
+    }
+    for (int i = 0; i < per; ++i)
+        if (base + (size_t)i * 256 < n4) out[base + (size_t)i * 256] = v;
 }
 
 __global__ void fill_linear(float4 *out, size_t n4) {
@@ -102,14 +135,83 @@ int main() {
         float t = timeit([&](float *o) { hipLaunchKernelGGL(fill_linear, dim3(2048), dim3(256), 0, 0, (float4 *)o, n / 4); }, 40);
         printf("linear fill (2048 x 256 threads, grid-stride float4): %.1f us  %.0f GB/s\n", t, n * 4 / t / 1e3);
     }
+    for (int per : {1, 2, 4, 8, 16, 64}) {
+        const size_t n4 = n / 4;
+        const unsigned grid = (unsigned)((n4 + 256ull * per - 1) / (256ull * per));
+        float t = timeit([&](float *o) { hipLaunchKernelGGL(fill_chunked, dim3(grid), dim3(256), 0, 0, (float4 *)o, n4, per); }, 40);
+        printf("chunked fill (%u blocks, %d float4 per thread): %.1f us  %.0f GB/s\n", grid, per, t, n * 4 / t / 1e3);
+    }
+    for (int layout = 0; layout < 2; ++layout)
+        for (int oi : {0, 2, 4}) {
+            const int lds_kb_[] = {80, 53, 40, 26, 20}, occ_[] = {2, 3, 4, 6, 8};
+            const int lds = lds_kb_[oi] * 1024, nwg = 256 * occ_[oi];
+            if (layout == 0) hipFuncSetAttribute((const void *)probe<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            else hipFuncSetAttribute((const void *)probe<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            auto launch = [&](float *o) {
+                if (layout == 0) hipLaunchKernelGGL((probe<0, true>), dim3(nwg), dim3(256), lds, 0, o, src, 0, 0);
+                else hipLaunchKernelGGL((probe<1, true>), dim3(nwg), dim3(256), lds, 0, o, src, 0, 0);
+            };
+            float t = timeit(launch, 24);
+            printf("NO LDS TRANSPOSE layout %d, %d WG/CU: %.1f us  %.0f GB/s\n", layout, occ_[oi], t, n * 4 / t / 1e3);
+        }
+    for (int varied = 0; varied < 2; ++varied)
+        for (int per : {1, 4}) {
+            const size_t n4 = n / 4;
+            const unsigned grid = (unsigned)((n4 + 256ull * per - 1) / (256ull * per));
+            float t = timeit([&](float *o) { hipLaunchKernelGGL(fill_chunked, dim3(grid), dim3(256), 0, 0, (float4 *)o, n4, per, varied); }, 40);
+            printf("DATA chunked fill per %d, %s data: %.1f us  %.0f GB/s\n", per, varied ? "hashed" : "constant", t, n * 4 / t / 1e3);
+        }
+    {
+        // the probe with all-equal data: src is zero, nfma=0 keeps og = tid + j; use kslices=-1 as "constant data" switch
+        const int lds = 80 * 1024, nwg = 512;
+        hipFuncSetAttribute((const void *)probe<0, false, -1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        auto launch = [&](float *o) { hipLaunchKernelGGL((probe<0, false, -1>), dim3(nwg), dim3(256), lds, 0, o, src, 0, 0, -1); };
+        float t = timeit(launch, 24);
+        printf("DATA probe stores only, constant data: %.1f us  %.0f GB/s\n", t, n * 4 / t / 1e3);
+        auto launch2 = [&](float *o) { hipLaunchKernelGGL((probe<0, false, -1>), dim3(nwg), dim3(256), lds, 0, o, src, 0, 0, 0); };
+        t = timeit(launch2, 24);
+        printf("DATA probe stores only, per-lane data: %.1f us  %.0f GB/s\n", t, n * 4 / t / 1e3);
+        return 0;
+    }
+    {
+        const int lds_kb_[] = {80, 53, 40, 26, 20}, occ_[] = {2, 3, 4, 6, 8};
+        for (int occi : {0, 2, 4}) {
+            const int lds = lds_kb_[occi] * 1024, nwg = 256 * occ_[occi];
+            for (int work = 0; work < 3; ++work) {
+                const int nf = work == 0 ? 0 : (work == 1 ? 128 : 256), nl = work ? 32 : 0;
+#define RUNW(WN)                                                                                                              \
+                {                                                                                                             \
+                    hipFuncSetAttribute((const void *)probe<0, false, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);  \
+                    auto launch = [&](float *o) { hipLaunchKernelGGL((probe<0, false, WN>), dim3(nwg), dim3(256), lds, 0, o, src, nf, nl, 0); }; \
+                    float t = timeit(launch, 24);                                                                             \
+                    printf("FLOWCTL vmcnt(%2d) %d WG/CU nfma %3d nlds %2d: %.1f us  %.0f GB/s\n", WN, occ_[occi], nf, nl, t, n * 4 / t / 1e3); \
+                }
+                RUNW(-1) RUNW(0) RUNW(2) RUNW(4) RUNW(8) RUNW(16)
+            }
+        }
+        return 0;
+    }
+    for (int occi : {0, 4})
+        for (int ks : {2, 3, 4, 6, 8, 12, 24}) {
+            const int lds_kb_[] = {80, 53, 40, 26, 20}, occ_[] = {2, 3, 4, 6, 8};
+            const int lds = lds_kb_[occi] * 1024, nwg = ITEMS * ks;
+            hipFuncSetAttribute((const void *)probe<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            for (int work = 0; work < 2; ++work) {
+                auto launch = [&](float *o) { hipLaunchKernelGGL((probe<0, false>), dim3(nwg), dim3(256), lds, 0, o, src, work ? 256 : 0, work ? 32 : 0, ks); };
+                float t = timeit(launch, 24);
+                printf("ITEM-ALIGNED lockstep: %2d slices (%4d WGs, %d WG/CU by LDS) %s: %.1f us  %.0f GB/s\n", ks, nwg, occ_[occi],
+                       work ? "nfma 256 nlds 32" : "stores only     ", t, n * 4 / t / 1e3);
+            }
+        }
+    return 0;
     // LDS per workgroup -> workgroups per CU: 80 KB -> 2, 53 KB -> 3, 40 KB -> 4, 26 KB -> 6, 20 KB -> 8
     const int lds_kb[] = {80, 53, 40, 26, 20};
     const int occ[] = {2, 3, 4, 6, 8};
     for (int layout = 0; layout < 2; ++layout)
-        for (int oi = 0; oi < 5; ++oi)
-            for (int nfma : {0, 128, 256, 512})
+        for (int oi : {0, 2})
+            for (int nfma : {0, 256})
                 for (int nlds : {0, 32}) {
-                    if ((nfma == 128 || nfma == 512) && nlds == 0) continue;
+                    
                     const int lds = lds_kb[oi] * 1024, nwg = 256 * occ[oi];
                     auto launch = [&](float *o) {
                         if (layout == 0) hipLaunchKernelGGL(probe<0>, dim3(nwg), dim3(256), lds, 0, o, src, nfma, nlds);

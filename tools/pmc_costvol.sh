@@ -12,8 +12,9 @@ PASSES=(
  "WRITE_SIZE"
  "FETCH_SIZE"
 )
+NP=${PMC_PASSES:-5}
 i=0
-for P in "${PASSES[@]}"; do
+for P in "${PASSES[@]:0:$NP}"; do
   rocprofv3 --kernel-trace --pmc $P --output-format csv -d /tmp/pmc_$i -o p -- python $ROOT/tools/bench_costvol.py --iters 5 "$@" > /tmp/pmc_$i.log 2>&1
   i=$((i+1))
 done
@@ -23,8 +24,8 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 dur = collections.defaultdict(list)
 for f in glob.glob("/tmp/pmc_*/p_counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        if "costvol" in r["Kernel_Name"]:
-            k = "fwd" if "costvol_fwd" in r["Kernel_Name"] else "bwd"
+        if "costvol" in r["Kernel_Name"] or "cl_fwd" in r["Kernel_Name"] or "cl_bwd" in r["Kernel_Name"]:
+            k = "fwd" if "_fwd" in r["Kernel_Name"] else "bwd"
             agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
             dur[k].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 lines = []
