@@ -249,6 +249,16 @@ int md_backproject(const float *depth, const float *invK, int Bs, int nk, int h,
 int md_project3d(const float *points, const float *K, const float *T, int Bs, int nk, int h, int w, float eps,
                  float *pix, md_stream_t stream);
 
+/* ---- per-kernel timing (measurement only; not part of the reference's interface) ---------------------------------
+ * md_kernel_timing_enable(1) makes the plane-sweep entry points attach a HIP start / stop event pair to their KERNEL dispatch
+ * (hipExtLaunchKernelGGL: the dispatch's own begin / end timestamps, on the launch stream; not the argument checks or memsets); md_kernel_timing_enable(0) stops and drops the records.
+ * md_kernel_timing_read(name, ...) synchronises the recorded events of entry point `name` ("md_costvol_fwd",
+ * "md_costvol_bwd", with _bf16 / _f16 suffixes) and returns their average / minimum duration in microseconds and their
+ * count (0 launches: avg = min = 0).  bench.py's roofline figure is read from here: events recorded from Python around
+ * the ctypes call also time the host's launch latency whenever the GPU has run dry (77 vs 57 us inside the training step). */
+int md_kernel_timing_enable(int on);
+int md_kernel_timing_read(const char *name, double *avg_us, double *min_us, int *launches);
+
 #ifdef __cplusplus
 }
 #endif

@@ -66,6 +66,9 @@ SIGNATURES = {
     "md_pose_matrix_bwd": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     "md_backproject": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "md_project3d": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp]),
+    "md_kernel_timing_enable": (_i, [_i]),
+    "md_kernel_timing_read": (_i, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
+                                   ctypes.POINTER(_i)]),
 }
 
 _lib = None

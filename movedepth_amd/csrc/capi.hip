@@ -13,7 +13,53 @@ void md_set_error(const char *fmt, ...) {
 }
 
 extern "C" const char *md_last_error(void) { return g_err; }
-extern "C" int md_abi_version(void) { return 9; }
+extern "C" int md_abi_version(void) { return 10; }
+
+// ---------------------------------------------------------------- per-kernel timing (measurement only)
+#include <vector>
+namespace {
+struct TimingRec { const char *name; hipEvent_t a, b; };
+bool g_timing = false;
+std::vector<TimingRec> g_recs;
+}  // namespace
+
+// A start / stop event pair for ONE kernel dispatch (hipExtLaunchKernelGGL ties them to the dispatch's own begin / end
+// timestamps -- the clock rocprofv3's kernel trace reads -- so host launch latency is not part of the interval); null, null
+// when timing is off.
+void md_timing_pair(const char *name, hipEvent_t *start, hipEvent_t *stop) {
+    *start = *stop = nullptr;
+    if (!g_timing) return;
+    TimingRec r{name, nullptr, nullptr};
+    if (hipEventCreate(&r.a) != hipSuccess) return;
+    if (hipEventCreate(&r.b) != hipSuccess) { (void)hipEventDestroy(r.a); return; }
+    g_recs.push_back(r);
+    *start = r.a;
+    *stop = r.b;
+}
+extern "C" int md_kernel_timing_enable(int on) {
+    for (auto &r : g_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    g_recs.clear();
+    g_timing = on != 0;
+    return MD_OK;
+}
+extern "C" int md_kernel_timing_read(const char *name, double *avg_us, double *min_us, int *launches) {
+    MD_REQUIRE(name && avg_us && min_us && launches, "md_kernel_timing_read: null argument");
+    double sum = 0.0, mn = 0.0;
+    int n = 0;
+    for (auto &r : g_recs) {
+        if (strcmp(r.name, name) != 0) continue;
+        float ms = 0.f;
+        if (hipEventSynchronize(r.b) != hipSuccess || hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) continue;
+        const double us = 1e3 * ms;
+        sum += us;
+        mn = (n == 0 || us < mn) ? us : mn;
+        ++n;
+    }
+    *avg_us = n ? sum / n : 0.0;
+    *min_us = mn;
+    *launches = n;
+    return MD_OK;
+}
 
 namespace {
 

@@ -701,21 +701,36 @@ int launch_cl_inst(const CvPtrs &q, const CvDims &dm, hipStream_t stream) {
     const long long total = (long long)dm.items * dm.D;
     long long nwg = env_int(BWD ? "MD_COSTVOL_NWG_BWD" : "MD_COSTVOL_NWG", 0);
     if (nwg <= 0) {
-        int per_cu = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64 * NW, 0) != hipSuccess || per_cu < 1) per_cu = 1;
-        int dev = 0, cus = 256;
-        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        nwg = (long long)cus * per_cu;
+        // resident workgroup slots of this kernel on this chip, queried once per instantiation (the query costs tens of
+        // microseconds of host time per call: with it in every launch the kernel started ~15 us late inside the training step)
+        static long long slots = 0;
+        if (slots == 0) {
+            int per_cu = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64 * NW, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+            int dev = 0, cus = 256;
+            if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+            slots = (long long)cus * per_cu;
+        }
+        // k equal hypothesis slices per item, the smallest k that fills every slot at least once (>= 8 steps per slice):
+        // item-aligned slices stage one window each; an arbitrary grid (e.g. exactly `slots`) makes most workgroups straddle
+        // two items and stage twice (B=6, 48x160, D=96: 720 workgroups 67.8 us, 512 72.8 us, 1024 82.7 us)
+        long long k = (slots + dm.items - 1) / dm.items;
+        if (k > dm.D / 8) k = dm.D / 8;
+        if (k < 1) k = 1;
+        nwg = (long long)dm.items * k;
     }
     if (nwg > total) nwg = total;
     if (nwg * ITV_MAX < total) nwg = (total + ITV_MAX - 1) / ITV_MAX;  // a share fits the interval table
     const dim3 grid((unsigned)nwg), block(64 * NW);
+    const char *tname = BWD ? MD_CV_STR(MD_CV_NAME(md_costvol_bwd)) : MD_CV_STR(MD_CV_NAME(md_costvol_fwd));
+    hipEvent_t ev0, ev1;
+    md_timing_pair(tname, &ev0, &ev1);
     if (BWD)
-        hipLaunchKernelGGL((cl_bwd_kernel<N, LPP, NW, FUSED>), grid, block, 0, stream, q.gout, q.ref, q.src, q.K, q.invK,
-                           q.pose, q.hyp, q.prior, q.ztrans, q.d_ref, q.d_src, dm);
+        hipExtLaunchKernelGGL((cl_bwd_kernel<N, LPP, NW, FUSED>), grid, block, 0, stream, ev0, ev1, 0, q.gout, q.ref, q.src,
+                              q.K, q.invK, q.pose, q.hyp, q.prior, q.ztrans, q.d_ref, q.d_src, dm);
     else
-        hipLaunchKernelGGL((cl_fwd_kernel<N, LPP, NW, FUSED>), grid, block, 0, stream, q.ref, q.src, q.K, q.invK, q.pose,
-                           q.hyp, q.prior, q.ztrans, q.out, dm);
+        hipExtLaunchKernelGGL((cl_fwd_kernel<N, LPP, NW, FUSED>), grid, block, 0, stream, ev0, ev1, 0, q.ref, q.src, q.K,
+                              q.invK, q.pose, q.hyp, q.prior, q.ztrans, q.out, dm);
     MD_CHECK_LAUNCH(BWD ? "md_costvol_bwd (channels-last)" : "md_costvol_fwd (channels-last)");
     return MD_OK;
 }
@@ -723,7 +738,9 @@ int launch_cl_inst(const CvPtrs &q, const CvDims &dm, hipStream_t stream) {
 template <bool BWD>
 int launch_cl(const CvPtrs &q, CvDims dm, hipStream_t stream) {
     const int N = dm.C / dm.G, LPP = dm.G / 4, TW = 64 / LPP;
-    const int NW = env_int(BWD ? "MD_COSTVOL_CL_NW_BWD" : "MD_COSTVOL_CL_NW", 8) == 4 ? 4 : 8;
+    // waves per workgroup: forward 8 (16 x 8 pixel tile), backward 4 (its LDS is 3x the source window per workgroup; measured at
+    // B=6, 48x160, D=96: backward 131 us with 4 against 152 with 8, forward 68 against 62)
+    const int NW = env_int(BWD ? "MD_COSTVOL_CL_NW_BWD" : "MD_COSTVOL_CL_NW", BWD ? 4 : 8) == 4 ? 4 : 8;
     dm.tiles_x = md_cdiv(dm.w, TW);
     dm.tiles = dm.tiles_x * md_cdiv(dm.h, NW);
     dm.splits = 1;
@@ -820,17 +837,21 @@ int launch(const CvPtrs &q, CvDims dm, hipStream_t stream) {
     const bool nhwc = !BWD && dm.sg == 1 && dm.G % 4 == 0 && dm.sb % 4 == 0 && dm.sd % 4 == 0 && dm.sp % 4 == 0 &&
                       ((uintptr_t)q.out % 16) == 0;
     (void)nhwc;
+    bool launched = true;
+    const char *tname = BWD ? MD_CV_STR(MD_CV_NAME(md_costvol_bwd)) : MD_CV_STR(MD_CV_NAME(md_costvol_fwd));
+    hipEvent_t ev0, ev1;
+    md_timing_pair(tname, &ev0, &ev1);
 
 #define MD_CV_LAUNCH(GS_, N_, TW_, F_)                                                                                \
     do {                                                                                                              \
         if (BWD)                                                                                                      \
-            hipLaunchKernelGGL((costvol_bwd_kernel<GS_, N_, TW_, F_>), grid, block, 0, stream, q.gout, q.ref, q.src,  \
-                               q.K, q.invK, q.pose, q.hyp, q.prior, q.ztrans, q.d_ref, q.d_src, dm);                  \
+            hipExtLaunchKernelGGL((costvol_bwd_kernel<GS_, N_, TW_, F_>), grid, block, 0, stream, ev0, ev1, 0, q.gout,   \
+                                  q.ref, q.src, q.K, q.invK, q.pose, q.hyp, q.prior, q.ztrans, q.d_ref, q.d_src, dm);   \
         else if (nhwc && (GS_) % 4 == 0)                                                                              \
-            hipLaunchKernelGGL((costvol_fwd_nhwc_kernel<((GS_) % 4 == 0 ? (GS_) : 4), N_, TW_, F_>), grid, block, 0,  \
-                               stream, q.ref, q.src, q.K, q.invK, q.pose, q.hyp, q.prior, q.ztrans, q.out, dm);       \
+            hipExtLaunchKernelGGL((costvol_fwd_nhwc_kernel<((GS_) % 4 == 0 ? (GS_) : 4), N_, TW_, F_>), grid, block, 0, \
+                               stream, ev0, ev1, 0, q.ref, q.src, q.K, q.invK, q.pose, q.hyp, q.prior, q.ztrans, q.out, dm);       \
         else                                                                                                          \
-            hipLaunchKernelGGL((costvol_fwd_kernel<GS_, N_, TW_, F_>), grid, block, 0, stream, q.ref, q.src, q.K,     \
+            hipExtLaunchKernelGGL((costvol_fwd_kernel<GS_, N_, TW_, F_>), grid, block, 0, stream, ev0, ev1, 0, q.ref, q.src, q.K,     \
                                q.invK, q.pose, q.hyp, q.prior, q.ztrans, q.out, dm);                                  \
     } while (0)
 #define MD_CV_F(GS_, N_, TW_)                        \
@@ -840,7 +861,6 @@ int launch(const CvPtrs &q, CvDims dm, hipStream_t stream) {
     } while (0)
 #define MD_CV_TW(GS_, N_) MD_CV_F(GS_, N_, 32)
 
-    bool launched = true;
     switch (N * 100 + CPW) {
         case 104: MD_CV_TW(4, 1); break;
         case 108: MD_CV_TW(8, 1); break;

@@ -1,6 +1,7 @@
 // Shared host/device helpers for libmovedepth_hip.so (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdarg.h>
 #include <stdio.h>
 
@@ -34,6 +35,9 @@ void md_set_error(const char *fmt, ...);
             return MD_ELAUNCH;                                                \
         }                                                                     \
     } while (0)
+
+// kernel timing hook (capi.hip): start / stop events for hipExtLaunchKernelGGL, null unless md_kernel_timing_enable(1)
+void md_timing_pair(const char *name, hipEvent_t *start, hipEvent_t *stop);
 
 static inline int md_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 

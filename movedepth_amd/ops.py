@@ -22,6 +22,21 @@ def enable_kernel_timing(names):
     KERNEL_EVENTS = {n: [] for n in names}
 
 
+def enable_library_kernel_timing(on=True):
+    """HIP events recorded INSIDE the library, directly around the plane-sweep kernel launches (md_kernel_timing_*)."""
+    _lib.call("md_kernel_timing_enable", int(bool(on)))
+
+
+def library_kernel_times_us(names):
+    out = {}
+    for n in names:
+        avg, mn, cnt = ctypes.c_double(), ctypes.c_double(), ctypes.c_int()
+        _lib.call("md_kernel_timing_read", n.encode(), ctypes.byref(avg), ctypes.byref(mn), ctypes.byref(cnt))
+        if cnt.value:
+            out[n] = {"avg_us": avg.value, "min_us": mn.value, "launches": cnt.value}
+    return out
+
+
 def kernel_times_us():
     """Average duration per timed entry point (call after torch.cuda.synchronize())."""
     out = {}

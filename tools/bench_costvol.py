@@ -99,12 +99,21 @@ def main():
     print("  ref (rotate=%d): zero_ of %.0f MB %.1f us (%.0f GB/s); copy_ (one buffer pair) %.1f us (%.0f GB/s r+w)" % (
         len(bigs), big.numel() * 4 / 1e6, t_fill, big.numel() * 4 / t_fill / 1e3, t_copy, 2 * big.numel() * 4 / t_copy / 1e3))
     del bigs
+    ops.enable_library_kernel_timing(True)
     tf = time_fn(fwd, a.iters)
     tb = time_fn(bwd, a.iters)
+    torch.cuda.synchronize()
+    sfx = {"f32": "", "bf16": "_bf16", "f16": "_f16"}[a.dtype]
+    lib_t = ops.library_kernel_times_us(["md_costvol_fwd" + sfx, "md_costvol_bwd" + sfx])
+    ops.enable_library_kernel_timing(False)
     env = {k: v for k, v in os.environ.items() if k.startswith("MD_")}
     print("costvol B=%d %dx%d D=%d C=%d G=%d fused=%d layout=%s dtype=%s prior=%s env=%s" % (B, h, w, D, C, G, a.fused, a.layout, a.dtype, a.prior, env))
     print("  fwd %8.1f us  %7.1f MB  %7.0f GB/s (%.1f%% of 8 TB/s)" % (tf, fbytes / 1e6, fbytes / tf / 1e3, fbytes / tf / 1e3 / 80))
     print("  bwd %8.1f us  %7.1f MB  %7.0f GB/s (%.1f%% of 8 TB/s)  [includes 2 memsets + autograd glue]" % (tb, bbytes / 1e6, bbytes / tb / 1e3, bbytes / tb / 1e3 / 80))
+    for k, v in lib_t.items():
+        nb = fbytes if "fwd" in k else bbytes
+        print("  kernel only (dispatch start/stop events inside the library) %-16s avg %7.1f us  min %7.1f us  %d launches  %.1f%% of 8 TB/s" % (
+            k, v["avg_us"], v["min_us"], v["launches"], nb / v["avg_us"] / 1e3 / 80))
 
 
 if __name__ == "__main__":

@@ -23,7 +23,7 @@ with open("$OUT", "w") as f:
     f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps %d --warmup %d  (%d steps; MIOpen caches warmed by a prior run)\n" % ($STEPS, $WARM, n))
     f.write("# total kernel time %.1f ms = %.2f ms per step; of that solver-search (naive_conv*) kernels %.1f ms\n" % (tot / 1e6, tot / 1e6 / n, naive / 1e6))
     f.write("name,calls,total_ms,ms_per_step,avg_us,min_us,max_us,percent\n")
-    mine = ("costvol", "warp_", "ssim_", "reproj_", "masked_min", "smooth_", "sel_", "schedule_", "fuse_", "disp_up", "conv3d_c")
+    mine = ("costvol", "cl_fwd", "cl_bwd", "warp_", "ssim_", "reproj_", "masked_min", "smooth_", "sel_", "schedule_", "fuse_", "disp_up", "conv3d_c")
     keep = rows[:45] + [r for r in rows[45:] if any(m in r["Name"] for m in mine)]
     for r in keep:
         f.write("\"%s\",%s,%.3f,%.3f,%.2f,%.2f,%.2f,%s\n" % (r["Name"][:140], r["Calls"], float(r["TotalDurationNs"]) / 1e6,
@@ -31,7 +31,7 @@ with open("$OUT", "w") as f:
 # categories
 cat = {"library 3-D conv (CK / naive)": ("ck::", "_ZN2ck", "naive_conv"), "library 2-D conv (Winograd / igemm)": ("miopenSp3AsmConv", "igemm_", "gemm_", "Cijk_"),
        "BatchNorm": ("BatchNorm",), "elementwise / copy / transpose / fill (torch, MIOpen)": ("elementwise", "transpose", "fillBuffer", "SubTensor", "copyBuffer", "CatArray", "reduce_kernel", "upsample", "reflection_pad", "index", "multi_tensor", "fused_adam"),
-       "hand-written: cost volume": ("costvol",), "hand-written: reg3d first/last conv": ("conv3d_c",),
+       "hand-written: cost volume": ("costvol", "cl_fwd_kernel", "cl_bwd_kernel"), "hand-written: reg3d first/last conv": ("conv3d_c",),
        "hand-written: fused BatchNorm+ReLU": ("bn_",),
        "hand-written: photometric + post-volume": ("warp_", "ssim_", "reproj_", "masked_min", "smooth_", "sel_", "schedule_", "fuse_", "disp_up", "convex", "backproject", "project3d")}
 acc = {k: 0.0 for k in cat}; other = 0.0
