@@ -181,6 +181,9 @@ def main():
         elapsed = float(t.item())
     times = ops.kernel_times_us()
     times.update(ops.library_kernel_times_us(["md_costvol_fwd" + sfx, "md_costvol_bwd" + sfx]))
+    if os.environ.get("MD_BENCH_DUMP_TIMES"):
+        for k_ in ("md_costvol_fwd" + sfx, "md_costvol_bwd" + sfx):
+            print(k_, " ".join("%.0f" % t for t in times.get(k_, {}).get("all_us", [])), file=sys.stderr)
     ops.enable_library_kernel_timing(False)
 
     if rank == 0:
@@ -207,7 +210,7 @@ def main():
                          "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (ach / HBM_PEAK_GBS) if ach else None,
                          "traffic": None, "traffic_from_profile": traffic_profile, "algorithmic_bytes_per_launch": fbytes,
                          "timing": "HIP events inside libmovedepth_hip.so around the kernel launch (md_kernel_timing_*)",
-                         "avg_launch_us": kt.get("avg_us"), "launches_timed": kt.get("launches"),
+                         "avg_launch_us": kt.get("avg_us"), "min_launch_us": kt.get("min_us"), "median_launch_us": kt.get("median_us"), "launches_timed": kt.get("launches"),
                          "bwd_avg_launch_us": times.get("md_costvol_bwd" + sfx, {}).get("avg_us")},
         }
         # the 3-D regulariser's first / last convolutions (hand-off either side of it), same live HIP-event timing:

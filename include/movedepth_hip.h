@@ -258,6 +258,8 @@ int md_project3d(const float *points, const float *K, const float *T, int Bs, in
  * the ctypes call also time the host's launch latency whenever the GPU has run dry (77 vs 57 us inside the training step). */
 int md_kernel_timing_enable(int on);
 int md_kernel_timing_read(const char *name, double *avg_us, double *min_us, int *launches);
+/* the individual durations, in launch order: fills us[0 .. min(n, cap)) and returns n (>= 0) */
+int md_kernel_timing_list(const char *name, double *us, int cap);
 
 #ifdef __cplusplus
 }

@@ -42,6 +42,18 @@ extern "C" int md_kernel_timing_enable(int on) {
     g_timing = on != 0;
     return MD_OK;
 }
+extern "C" int md_kernel_timing_list(const char *name, double *us, int cap) {
+    MD_REQUIRE(name && (us || cap == 0), "md_kernel_timing_list: null argument");
+    int n = 0;
+    for (auto &r : g_recs) {
+        if (strcmp(r.name, name) != 0) continue;
+        float ms = 0.f;
+        if (hipEventSynchronize(r.b) != hipSuccess || hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) continue;
+        if (n < cap) us[n] = 1e3 * ms;
+        ++n;
+    }
+    return n;
+}
 extern "C" int md_kernel_timing_read(const char *name, double *avg_us, double *min_us, int *launches) {
     MD_REQUIRE(name && avg_us && min_us && launches, "md_kernel_timing_read: null argument");
     double sum = 0.0, mn = 0.0;

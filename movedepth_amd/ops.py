@@ -33,7 +33,11 @@ def library_kernel_times_us(names):
         avg, mn, cnt = ctypes.c_double(), ctypes.c_double(), ctypes.c_int()
         _lib.call("md_kernel_timing_read", n.encode(), ctypes.byref(avg), ctypes.byref(mn), ctypes.byref(cnt))
         if cnt.value:
-            out[n] = {"avg_us": avg.value, "min_us": mn.value, "launches": cnt.value}
+            buf = (ctypes.c_double * cnt.value)()
+            _lib.load().md_kernel_timing_list(n.encode(), buf, cnt.value)
+            ts = sorted(buf)
+            out[n] = {"avg_us": avg.value, "min_us": mn.value, "median_us": ts[len(ts) // 2], "launches": cnt.value,
+                      "all_us": list(buf)}
     return out
 
 

@@ -1,6 +1,5 @@
-run() { echo "=== $*: $(env "$@" python tools/bench_costvol.py --layout ndhwc --iters 30 2>&1 | grep -E "kernel only" | cut -c62-130 | tr '\n' ' ')"; }
-for nwg in 0 720 768 1080 1440; do
-run PRIOR=smooth MD_COSTVOL_NWG=$nwg
+for e in "X=0" "X=1" "X=2"; do
+echo "=== $e: $(env $e python bench.py --no_cpu_baseline 2>/dev/null | python -c "
+import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']; print(round(d['ms_per_step'],2), round(r['avg_launch_us'],1), round(r['bwd_avg_launch_us'],1), r.get('min_launch_us'))")"
 done
-run PRIOR=white MD_COSTVOL_NWG=720
-run PRIOR=const PRIOR_CONST=0.21 POSE_TX=0.002 POSE_TZ=0.001 MD_COSTVOL_NWG=720
+rocm-smi --showclocks 2>/dev/null | head -20
