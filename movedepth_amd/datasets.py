@@ -1,0 +1,130 @@
+"""KITTI-layout producer of the trainer's input dictionary, without torchvision / cv2 / skimage.
+
+What the reference's `MonoDataset.__getitem__` + `KITTIRAWDataset` hand to `Trainer.process_batch`
+(datasets/mono_dataset.py:134-237, datasets/kitti_dataset.py:19-90), reproduced from its contract:
+
+  ("color", f, s), ("color_aug", f, s)   float32 in [0, 1], (3, H // 2**s, W // 2**s), f in frame_idxs, s in 0..num_scales-1;
+                                          scale s is a LANCZOS resize of scale s-1 (s = 0: of the frame as stored on disk);
+  ("K", s), ("inv_K", s)                  (4, 4) float32: KITTI's normalised intrinsics (kitti_dataset.py:26-29) with row 0 times
+                                          W // 2**s and row 1 times H // 2**s (integer division, mono_dataset.py:212-213),
+                                          inv_K = pinv(K);
+  training only, each with probability 1/2 and the SAME draw for every frame of the item: horizontal flip; colour jitter
+  (brightness, contrast, saturation in [0.8, 1.2], hue in [-0.1, 0.1], applied in a random order) on "color_aug" only;
+  an all-black frame keeps color_aug = color; a neighbouring frame missing on disk is replaced by the frame next to it.
+
+File layout: <data_path>/<folder>/image_0{2,3}/data/<frame:010d><ext>, split lines "<folder> <frame> <l|r>".
+Not produced: "depth_gt" (needs the velodyne projection of kitti_utils.py, out of scope: it is only read by the monitoring
+metrics) and ('relative_pose', f) (DVSO poses, `--load_pose`).  The random draws are this module's own (a numpy Generator):
+the reference draws through torchvision, whose stream cannot be matched without it; the distribution is the same.
+"""
+import os
+
+import numpy as np
+import torch
+from PIL import Image, ImageEnhance
+
+KITTI_K = np.array([[0.58, 0, 0.5, 0], [0, 1.92, 0.5, 0], [0, 0, 1, 0], [0, 0, 0, 1]], dtype=np.float32)
+_SIDE = {"2": 2, "3": 3, "l": 2, "r": 3}
+
+
+def read_split(path):
+    with open(path) as f:
+        return f.read().splitlines()
+
+
+def _to_tensor(img):
+    a = np.asarray(img, dtype=np.uint8)
+    return torch.from_numpy(np.ascontiguousarray(a.transpose(2, 0, 1))).float().div_(255.0)
+
+
+def _shift_hue(img, h):
+    """hue shift by h in [-0.5, 0.5] turns of the colour wheel, as PIL-image colour jitter does it (8-bit HSV)."""
+    hsv = np.array(img.convert("HSV"), dtype=np.uint8)
+    hsv[..., 0] = (hsv[..., 0].astype(np.int16) + int(round(h * 255))) % 256
+    return Image.fromarray(hsv, "HSV").convert("RGB")
+
+
+class ColorJitter:
+    """One draw of (brightness, contrast, saturation, hue, order); calling it applies that draw to an image."""
+
+    def __init__(self, rng, brightness=(0.8, 1.2), contrast=(0.8, 1.2), saturation=(0.8, 1.2), hue=(-0.1, 0.1)):
+        self.b, self.c, self.s = (float(rng.uniform(*r)) for r in (brightness, contrast, saturation))
+        self.h = float(rng.uniform(*hue))
+        self.order = rng.permutation(4)
+
+    def __call__(self, img):
+        for op in self.order:
+            if op == 0:
+                img = ImageEnhance.Brightness(img).enhance(self.b)
+            elif op == 1:
+                img = ImageEnhance.Contrast(img).enhance(self.c)
+            elif op == 2:
+                img = ImageEnhance.Color(img).enhance(self.s)
+            else:
+                img = _shift_hue(img, self.h)
+        return img
+
+
+class KITTIRAWDataset(torch.utils.data.Dataset):
+    def __init__(self, data_path, filenames, height, width, frame_idxs, num_scales, is_train=False, img_ext=".jpg", seed=0):
+        self.data_path, self.filenames = data_path, list(filenames)
+        self.height, self.width = int(height), int(width)
+        self.frame_idxs, self.num_scales = list(frame_idxs), int(num_scales)
+        self.is_train, self.img_ext = bool(is_train), img_ext
+        self.K = KITTI_K
+        self.rng = np.random.default_rng(seed)
+
+    def __len__(self):
+        return len(self.filenames)
+
+    def image_path(self, folder, frame_index, side):
+        return os.path.join(self.data_path, folder, "image_0%d/data" % _SIDE[side], "%010d%s" % (frame_index, self.img_ext))
+
+    def _load(self, folder, frame_index, side, flip):
+        with open(self.image_path(folder, frame_index, side), "rb") as f:
+            img = Image.open(f).convert("RGB")
+        return img.transpose(Image.FLIP_LEFT_RIGHT) if flip else img
+
+    def __getitem__(self, index):
+        parts = self.filenames[index].split()
+        folder = parts[0]
+        frame_index, side = (int(parts[1]), parts[2]) if len(parts) == 3 else (0, None)
+        do_aug = self.is_train and self.rng.random() > 0.5
+        do_flip = self.is_train and self.rng.random() > 0.5
+        native = {}
+        for i in self.frame_idxs:
+            try:
+                native[i] = self._load(folder, frame_index + i, side, do_flip)
+            except FileNotFoundError:
+                if i == 0:
+                    raise FileNotFoundError("cannot find frame %s: check --data_path / --png" %
+                                            self.image_path(folder, frame_index, side))
+                native[i] = native[i - 1 if i > 0 else i + 1]  # sequence end: repeat the neighbour (mono_dataset.py:196-199)
+        jitter = ColorJitter(self.rng) if do_aug else (lambda im: im)
+        inputs = {}
+        for i in self.frame_idxs:
+            img = native[i]
+            for s in range(self.num_scales):
+                img = img.resize((self.width // 2 ** s, self.height // 2 ** s), Image.LANCZOS)  # from the previous scale
+                t = _to_tensor(img)
+                inputs[("color", i, s)] = t
+                inputs[("color_aug", i, s)] = t if float(t.sum()) == 0 else _to_tensor(jitter(img))
+        for s in range(self.num_scales):
+            K = self.K.copy()
+            K[0, :] *= self.width // (2 ** s)
+            K[1, :] *= self.height // (2 ** s)
+            inputs[("K", s)] = torch.from_numpy(K)
+            inputs[("inv_K", s)] = torch.from_numpy(np.linalg.pinv(K))
+        return inputs
+
+
+def make_loader(dataset, batch_size, rank=0, world_size=1, shuffle=True, num_workers=0, seed=0, drop_last=True):
+    """DataLoader over `dataset` with the reference's sharding (one DistributedSampler-style rank-strided shard per process,
+    trainer.py:171-179; drop_last as there).  Returns (loader, sampler-or-None): call sampler.set_epoch(e) per epoch."""
+    sampler = None
+    if world_size > 1:
+        sampler = torch.utils.data.distributed.DistributedSampler(dataset, num_replicas=world_size, rank=rank, shuffle=shuffle,
+                                                                  seed=seed)
+    loader = torch.utils.data.DataLoader(dataset, batch_size, shuffle=(shuffle and sampler is None), sampler=sampler,
+                                         num_workers=num_workers, pin_memory=True, drop_last=drop_last)
+    return loader, sampler

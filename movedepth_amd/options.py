@@ -11,7 +11,11 @@ class MonodepthOptions:
         p = argparse.ArgumentParser(description="MOVEDepth (MI355X hot path) options")
         # paths / bookkeeping
         p.add_argument("--data_path", type=str, default="synthetic",
-                       help="'synthetic' (default: seeded synthetic KITTI-shaped frames); KITTI loading is out of scope")
+                       help="'synthetic' (default: seeded synthetic KITTI-shaped frames) or the root of a KITTI raw tree "
+                            "(<date>/<drive>_sync/image_0{2,3}/data/*.jpg), read by movedepth_amd.datasets")
+        p.add_argument("--train_files", type=str, default=None,
+                       help="split file ('<folder> <frame> <l|r>' per line) when --data_path is a KITTI tree; default "
+                            "<data_path>/splits/<split>/train_files.txt")
         p.add_argument("--log_dir", type=str, default=os.path.join(os.path.expanduser("~"), "tmp"))
         p.add_argument("--model_name", type=str, default="mdp")
         p.add_argument("--split", type=str, default="eigen_zhou")

@@ -157,8 +157,18 @@ class Trainer:
             self.grad_sync = GradSync(self.parameters_to_train + self.mvs_parameters_to_train, opt.grad_bucket_mb)
             opt.log_frequency = max(1, opt.log_frequency // self.world_size)
 
-        self.train_loader = SyntheticLoader(opt.batch_size, opt.height, opt.width, opt.frame_ids, opt.steps_per_epoch,
-                                            self.rank, self.world_size, device="cpu")
+        self.train_sampler = None
+        if opt.data_path == "synthetic":
+            self.train_loader = SyntheticLoader(opt.batch_size, opt.height, opt.width, opt.frame_ids, opt.steps_per_epoch,
+                                                self.rank, self.world_size, device="cpu")
+        else:
+            # KITTI raw layout, the reference's sharding (trainer.py:166-179): one rank-strided shard per process, drop_last
+            from . import datasets
+            split = opt.train_files or os.path.join(opt.data_path, "splits", opt.split, "train_files.txt")
+            train = datasets.KITTIRAWDataset(opt.data_path, datasets.read_split(split), opt.height, opt.width, opt.frame_ids,
+                                             4, is_train=True, img_ext=".png" if opt.png else ".jpg", seed=self.rank)
+            self.train_loader, self.train_sampler = datasets.make_loader(train, opt.batch_size, self.rank, self.world_size,
+                                                                         shuffle=True, num_workers=opt.num_workers)
         self.num_total_steps = len(self.train_loader) * opt.num_epochs
         self.depth_metric_names = ["de/abs_rel", "de/sq_rel", "de/rms", "de/log_rms", "da/a1", "da/a2", "da/a3"]
         self.epoch, self.step = 0, 0
@@ -178,7 +188,10 @@ class Trainer:
         self.epoch, self.step = 0, 0
         self.start_time = time.time()
         for self.epoch in range(self.opt.num_epochs):
-            self.train_loader.set_epoch(self.epoch)
+            if self.train_sampler is not None:
+                self.train_sampler.set_epoch(self.epoch)
+            elif hasattr(self.train_loader, "set_epoch"):
+                self.train_loader.set_epoch(self.epoch)
             self.run_epoch()
             if (self.epoch + 1) % self.opt.save_frequency == 0 and self.epoch > 15:
                 self.save_model()

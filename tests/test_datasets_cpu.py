@@ -1,0 +1,135 @@
+"""Input-dictionary contract (reference datasets/mono_dataset.py:134-237, kitti_dataset.py:19-90) of the two
+producers: movedepth_amd.datasets.KITTIRAWDataset on a KITTI-layout tree written into a temporary directory, and
+movedepth_amd.synthetic.make_inputs.  CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+from movedepth_amd import datasets
+from movedepth_amd.synthetic import make_inputs
+
+H, W = 64, 128
+FRAMES = [0, -1, 1]
+
+
+def _write_tree(root, n_frames=5, ext=".png", blank=None):
+    folder = "2011_09_26/2011_09_26_drive_0001_sync"
+    rng = np.random.default_rng(5)
+    for side in (2, 3):
+        d = os.path.join(root, folder, "image_0%d" % side, "data")
+        os.makedirs(d)
+        for i in range(n_frames):
+            coarse = rng.integers(0, 255, (12, 40, 3), dtype=np.uint8)
+            img = Image.fromarray(coarse).resize((310, 94), Image.BILINEAR)  # KITTI aspect (1242x375 / 4)
+            if blank == i:
+                img = Image.new("RGB", (310, 94))
+            img.save(os.path.join(d, "%010d%s" % (i, ext)))
+    return folder
+
+
+def _expected_K(s):
+    K = np.array([[0.58, 0, 0.5, 0], [0, 1.92, 0.5, 0], [0, 0, 1, 0], [0, 0, 0, 1]], np.float32)
+    K[0] *= W // 2 ** s
+    K[1] *= H // 2 ** s
+    return K
+
+
+def _check_contract(item, batch=None):
+    keys = set(item.keys())
+    want = {(n, f, s) for n in ("color", "color_aug") for f in FRAMES for s in range(4)} | \
+           {(n, s) for n in ("K", "inv_K") for s in range(4)}
+    assert keys == want
+    lead = () if batch is None else (batch,)
+    for f in FRAMES:
+        for s in range(4):
+            for n in ("color", "color_aug"):
+                t = item[(n, f, s)]
+                assert t.dtype == torch.float32 and tuple(t.shape) == lead + (3, H // 2 ** s, W // 2 ** s)
+                assert float(t.min()) >= 0.0 and float(t.max()) <= 1.0
+    for s in range(4):
+        K, iK = item[("K", s)], item[("inv_K", s)]
+        assert K.dtype == torch.float32 and tuple(K.shape) == lead + (4, 4)
+        Kn = K.numpy().reshape(-1, 4, 4)[0]
+        np.testing.assert_array_equal(Kn, _expected_K(s))                       # W // 2**s, not W / 2**s
+        np.testing.assert_allclose(iK.numpy().reshape(-1, 4, 4)[0], np.linalg.pinv(Kn), rtol=1e-6, atol=1e-9)
+
+
+def test_kitti_layout_eval_item(tmp_path):
+    folder = _write_tree(str(tmp_path))
+    ds = datasets.KITTIRAWDataset(str(tmp_path), ["%s 2 l" % folder, "%s 1 r" % folder], H, W, FRAMES, 4, is_train=False,
+                                  img_ext=".png")
+    assert len(ds) == 2
+    item = ds[0]
+    _check_contract(item)
+    for f in FRAMES:
+        for s in range(4):
+            assert torch.equal(item[("color", f, s)], item[("color_aug", f, s)])    # no augmentation outside training
+    # scale 0 is the stored frame resized with LANCZOS; scale s is scale s-1 resized again
+    with Image.open(ds.image_path(folder, 2 - 1, "l")) as im:
+        ref0 = im.convert("RGB").resize((W, H), Image.LANCZOS)
+    np.testing.assert_array_equal((item[("color", -1, 0)].numpy() * 255).round().astype(np.uint8),
+                                  np.asarray(ref0).transpose(2, 0, 1))
+    ref1 = ref0.resize((W // 2, H // 2), Image.LANCZOS)
+    np.testing.assert_array_equal((item[("color", -1, 1)].numpy() * 255).round().astype(np.uint8),
+                                  np.asarray(ref1).transpose(2, 0, 1))
+    # "r" reads image_03
+    r = ds[1]
+    with Image.open(os.path.join(str(tmp_path), folder, "image_03/data", "%010d.png" % 1)) as im:
+        np.testing.assert_array_equal((r[("color", 0, 0)].numpy() * 255).round().astype(np.uint8),
+                                      np.asarray(im.convert("RGB").resize((W, H), Image.LANCZOS)).transpose(2, 0, 1))
+
+
+def test_kitti_layout_sequence_ends_and_blank_frames(tmp_path):
+    folder = _write_tree(str(tmp_path), n_frames=3, blank=1)
+    ds = datasets.KITTIRAWDataset(str(tmp_path), ["%s 0 l" % folder, "%s 2 l" % folder, "%s 7 l" % folder], H, W, FRAMES, 4,
+                                  is_train=True, img_ext=".png", seed=3)
+    first = ds[0]                                     # frame -1 does not exist: replaced by its neighbour (frame 0)
+    assert torch.equal(first[("color", -1, 0)], first[("color", 0, 0)])
+    last = ds[1]                                      # frame 3 does not exist: frame +1 := frame 0 of the item (= stored 2)
+    assert torch.equal(last[("color", 1, 0)], last[("color", 0, 0)])
+    with pytest.raises(FileNotFoundError):
+        ds[2]
+    # the all-black stored frame 1 keeps color_aug == color whatever the jitter draw
+    for it in (first, last):
+        for f in FRAMES:
+            if float(it[("color", f, 0)].sum()) == 0:
+                assert float(it[("color_aug", f, 0)].sum()) == 0
+
+
+def test_training_augmentation_is_shared_by_the_frames_of_an_item(tmp_path):
+    folder = _write_tree(str(tmp_path))
+    lines = ["%s 2 l" % folder] * 24
+    plain = datasets.KITTIRAWDataset(str(tmp_path), lines, H, W, FRAMES, 4, is_train=False, img_ext=".png")[0]
+    ds = datasets.KITTIRAWDataset(str(tmp_path), lines, H, W, FRAMES, 4, is_train=True, img_ext=".png", seed=11)
+    seen = set()
+    for i in range(24):
+        it = ds[i]
+        _check_contract(it)
+        flipped = torch.equal(it[("color", 0, 0)], torch.flip(plain[("color", 0, 0)], dims=[2])) and \
+            not torch.equal(it[("color", 0, 0)], plain[("color", 0, 0)])
+        for f in FRAMES:   # the flip is one draw for the whole item; LANCZOS of a mirrored image is the mirrored LANCZOS
+            want = torch.flip(plain[("color", f, 0)], dims=[2]) if flipped else plain[("color", f, 0)]
+            assert torch.equal(it[("color", f, 0)], want)
+        jittered = not torch.equal(it[("color_aug", 0, 0)], it[("color", 0, 0)])
+        for f in FRAMES:   # ... and so is the colour jitter: either every frame is jittered or none
+            assert (not torch.equal(it[("color_aug", f, 0)], it[("color", f, 0)])) == jittered
+        seen.add((flipped, jittered))
+    assert len(seen) == 4   # both coins land both ways within 24 draws
+
+
+def test_loader_batches_and_shards(tmp_path):
+    folder = _write_tree(str(tmp_path))
+    lines = ["%s %d l" % (folder, i) for i in (1, 2, 3)] * 4
+    ds = datasets.KITTIRAWDataset(str(tmp_path), lines, H, W, FRAMES, 4, is_train=True, img_ext=".png")
+    loader, sampler = datasets.make_loader(ds, 2, rank=1, world_size=2, shuffle=True, seed=0)
+    assert sampler is not None and len(loader) == 3          # 12 items / 2 ranks / batch 2, drop_last
+    batch = next(iter(loader))
+    _check_contract(batch, batch=2)
+
+
+def test_synthetic_producer_honours_the_same_contract():
+    item = make_inputs(2, H, W, FRAMES, seed=1)
+    _check_contract(item, batch=2)

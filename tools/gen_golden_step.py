@@ -34,7 +34,8 @@ from refload import load_reference  # noqa: E402
 
 OUT = os.path.join(ROOT, "tests", "golden")
 
-from step_fixture import B, H, W, D, STEP_SEED, WEIGHT_SEED, BASE_ARGS, CASES, build_weights, make_frames, checksums  # noqa: E402
+from step_fixture import (B, H, W, D, STEP_SEED, WEIGHT_SEED, BASE_ARGS, CASES, build_weights, make_frames, checksums,  # noqa: E402
+                          formula_state)
 
 
 def save(name, d):
@@ -253,12 +254,70 @@ def gen_ckpt_manifest(networks, L):
         m["mvs_encoder"] = networks.FPN4(base_channels=8, scale=opt.prior_scale, dcn=False)
         m["reg3d"] = networks.reg3d(in_channels=opt.reg3d_c, base_channels=opt.reg3d_c, down_size=3)
         m["up"] = L.convex_upsample_layer(feature_dim=8 * 2 ** opt.prior_scale, scale=opt.prior_scale)
-        man["res%d" % arch] = {k: {kk: [str(v.dtype).replace("torch.", "")] + list(v.shape) for kk, v in mod.state_dict().items()}
+        # per sub-model: the state_dict entries IN ORDER, [key, dtype, dim0, dim1, ...]
+        man["res%d" % arch] = {k: [[kk, str(v.dtype).replace("torch.", "")] + list(v.shape) for kk, v in mod.state_dict().items()]
                                for k, mod in m.items()}
     man["files"] = ["mono_encoder", "mono_depth", "pose_encoder", "pose", "mask_cnn", "mvs_encoder", "reg3d", "up", "adam"]
     path = os.path.join(OUT, "ckpt_manifest.json")
-    json.dump(man, open(path, "w"), indent=0, sort_keys=True)
+    json.dump(man, open(path, "w"), separators=(",", ":"))
     print("%-28s %8.1f KB" % ("ckpt_manifest.json", os.path.getsize(path) / 1024))
+
+
+def gen_networks_forward(networks, L):
+    """Every sub-model class of the reference (networks/*.py, layers.convex_upsample_layer) with formula weights
+    (step_fixture.formula_state), forward in training mode on seeded inputs: the outputs this repo's own network
+    definitions must reproduce from the same formula (tests/test_networks_cpu.py)."""
+    g = torch.Generator().manual_seed(31)
+    img = torch.rand(2, 3, 64, 128, generator=g)
+    pair = torch.rand(2, 6, 64, 128, generator=g)
+    d = {"img": img, "pair": pair}
+
+    def load(m):
+        m.load_state_dict(formula_state(m.state_dict()), strict=True)
+        return m.train()
+
+    def summarise(prefix, t):
+        d[prefix] = t if t.numel() <= 20000 else t.flatten()[:: max(1, t.numel() // 4096)][:4096].clone()
+        d[prefix + ":sums"] = torch.tensor([float(t.double().sum()), float(t.double().abs().sum())], dtype=torch.float64)
+
+    for arch in (18, 50):
+        enc = load(networks.ResnetEncoder(arch, False))
+        feats = enc(img)
+        for i, f in enumerate(feats):
+            summarise("enc%d_f%d" % (arch, i), f)
+        dec = load(networks.DepthDecoder(enc.num_ch_enc, [0, 1, 2, 3], match_conv=False, ddv=False, discret=None,
+                                         mono_conf=False, mono_bins=False))
+        out = dec(feats, no_match=False)
+        for s_ in range(4):
+            summarise("disp%d_s%d" % (arch, s_), out[("disp", s_)])
+        penc = load(networks.ResnetEncoder(arch, False, num_input_images=2))
+        pf = penc(pair)
+        summarise("penc%d_f4" % arch, pf[-1])
+        pdec = load(networks.PoseDecoder(penc.num_ch_enc, num_input_features=1, num_frames_to_predict_for=2))
+        aa, tr = pdec([pf])
+        summarise("pose%d_aa" % arch, aa)
+        summarise("pose%d_tr" % arch, tr)
+    fpn = load(networks.FPN4(base_channels=8, scale=2, dcn=False))
+    mf, cf = fpn(img)
+    summarise("fpn_match", mf)
+    summarise("fpn_context", cf)
+    unc = load(networks.UncertNet())
+    ent = torch.rand(2, 1, 16, 32, generator=g)
+    d["entropy"] = ent
+    summarise("uncert", unc(ent))
+    r3 = load(networks.reg3d(in_channels=16, base_channels=16, down_size=3))
+    vol = torch.randn(1, 16, 16, 16, 32, generator=g) * 0.1   # B D G h w
+    d["vol"] = vol
+    summarise("reg3d", r3(vol))
+    r2 = load(networks.reg2d(input_channel=16, base_channel=8))
+    vol2 = torch.randn(1, 4, 16, 16, 32, generator=g) * 0.1
+    d["vol2"] = vol2
+    summarise("reg2d", r2(vol2))
+    up = load(L.convex_upsample_layer(feature_dim=32, scale=2))
+    dep = 2 + torch.rand(2, 16, 32, generator=g)
+    d["up_depth"] = dep
+    summarise("up", up(dep, cf))
+    save("networks_forward", d)
 
 
 def main():
@@ -281,6 +340,7 @@ def main():
     save("step_inputs", fx)
     gen_eval(L, networks, frames)
     gen_ckpt_manifest(networks, L)
+    gen_networks_forward(networks, L)
 
 
 if __name__ == "__main__":

@@ -57,3 +57,23 @@ def checksums(models):
         out[name] = np.array([[float(v.double().sum()), float(v.double().abs().sum())] for k, v in sorted(sd.items())
                               if v.dtype.is_floating_point], np.float64)
     return out
+
+
+def formula_state(sd):
+    """Deterministic weights for ANY module from its state_dict key order alone (so that the reference's classes and this
+    repo's, built independently, can be given identical numbers without shipping them): entry i gets
+    scale * sin(0.618 * arange(n) + i), BatchNorm scale / variance entries 1 + 0.1 * (that), integer buffers untouched."""
+    out = {}
+    for i, (k, v) in enumerate(sd.items()):
+        if not v.dtype.is_floating_point:
+            out[k] = v.clone()
+            continue
+        n = v.numel()
+        base = torch.sin(0.618 * torch.arange(n, dtype=torch.float64) + i).reshape(v.shape)
+        if k.endswith("running_var") or (v.dim() == 1 and k.endswith(".weight")):
+            t = 1.0 + 0.1 * base
+        else:
+            fan = max(1, n // max(1, v.shape[0])) if v.dim() > 1 else 1
+            t = base * (1.5 / fan ** 0.5 if v.dim() > 1 else 0.1)
+        out[k] = t.to(v.dtype)
+    return out
