@@ -100,6 +100,7 @@ def main():
     ap.add_argument("--batch_per_gpu", type=int, default=6)
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--trainer_args", default="", help="extra movedepth_amd options, e.g. '--hip_prob_conv 0' for an A/B")
+    ap.add_argument("--epoch", type=int, default=0, help="trainer.epoch during the run (> ztrans_start_epc: velocity-guided bins)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -149,6 +150,7 @@ def main():
     with contextlib.redirect_stdout(sys.stderr):  # the trainer's banner (reference trainer.py:163-165) must not share
         trainer = Trainer(opt)                     # stdout with the one JSON line
     trainer.set_train()
+    trainer.epoch = a.epoch
     dev = trainer.device
     inputs = make_inputs(opt.batch_size, opt.height, opt.width, opt.frame_ids, seed=rank, device=dev)  # resident in HBM
 
@@ -168,6 +170,9 @@ def main():
     # 77 vs 57 us for the forward inside this step); the long convolution kernels keep the Python-side events
     ops.enable_kernel_timing(CONV_KERNELS)
     ops.enable_library_kernel_timing(True)
+    if os.environ.get("MD_CV_STATS"):   # diagnostics: work counters of the plane-sweep kernels over the timed steps
+        from movedepth_amd import _lib as _l
+        _l.load().md_costvol_stats(1, None)
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -179,6 +184,13 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    if os.environ.get("MD_CV_STATS"):
+        import ctypes as _ct
+        _buf = (_ct.c_ulonglong * 8)()
+        _l.load().md_costvol_stats(0, _buf)
+        print("costvol stats over %d steps (fwd+bwd launches together): segments %d, windows staged %d, fit attempts %d, "
+              "lanes redoing misses %d, cell-change blocks %d (%.1f lanes each), wave-steps %d" % (
+                  a.steps, _buf[0], _buf[1], _buf[2], _buf[3], _buf[4], _buf[5] / max(_buf[4], 1), _buf[6]), file=sys.stderr)
     times = ops.kernel_times_us()
     times.update(ops.library_kernel_times_us(["md_costvol_fwd" + sfx, "md_costvol_bwd" + sfx]))
     if os.environ.get("MD_BENCH_DUMP_TIMES"):
@@ -199,12 +211,18 @@ def main():
         if os.path.exists(pmc) and not sfx:   # the counter file was collected for the fp32 kernel
             traffic_profile = json.load(open(pmc))
         out = {
-            "metric": "train-step images/sec at 192x640, D=96; cost-volume HBM GB/s vs roofline",
+            "metric": "train-step images/sec at 192x640, D=96; cost-volume HBM GB/s vs roofline" if not a.trainer_args else
+                      "train-step images/sec at %dx%d, D=%d; cost-volume HBM GB/s vs roofline" % (opt.height, opt.width, opt.num_depth_bins),
             "value": gb * a.steps / elapsed, "unit": "images/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": {"none": "f32", "bf16": "bf16", "fp16": "f16"}[opt.amp], "data": "synthetic",
-            "config": {"workload": "BASELINE config %d: KITTI 192x640, ResNet18, D=96, batch %d/GPU, fp32, 2-frame cost "
-                                   "volume, process_batch+backward+Adam" % (2 if world == 1 else 3, opt.batch_size),
+            "config": {"workload": ("BASELINE config %d: " % (2 if world == 1 else 3) if not a.trainer_args else "") +
+                                   "KITTI %dx%d, ResNet%d, D=%d, batch %d/GPU, %s, %d-frame cost volume%s, "
+                                   "process_batch+backward+Adam%s" % (
+                                       opt.height, opt.width, opt.res_arch, opt.num_depth_bins, opt.batch_size,
+                                       {"none": "fp32", "bf16": "bf16 autocast", "fp16": "fp16 autocast"}[opt.amp],
+                                       len(opt.matching_ids), ", velocity-guided bins" if a.epoch > opt.ztrans_start_epc else "",
+                                       (" [" + a.trainer_args + "]") if a.trainer_args else ""),
                        "global_batch": gb, "parallelism": "dp%d" % world, "final_loss": loss_val},
             "roofline": {"bound": "hbm", "kernel": "md_costvol_fwd%s (plane-sweep cost volume, fused schedule + group mean)" % sfx,
                          "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (ach / HBM_PEAK_GBS) if ach else None,

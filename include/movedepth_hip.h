@@ -258,6 +258,11 @@ int md_project3d(const float *points, const float *K, const float *T, int Bs, in
  * the ctypes call also time the host's launch latency whenever the GPU has run dry (77 vs 57 us inside the training step). */
 int md_kernel_timing_enable(int on);
 int md_kernel_timing_read(const char *name, double *avg_us, double *min_us, int *launches);
+/* Work counters of the channels-last plane-sweep kernels (diagnostics).  md_costvol_stats(1, NULL) switches them on and clears
+ * them; md_costvol_stats(on, out8) first synchronises the device and copies the 8 counters accumulated so far: [0] segments,
+ * [1] windows staged (sub-slices), [2] window-fit attempts, [3] (lane, sub-slice) pairs that had to redo steps from global memory, [4] wave-level
+ * cell-change blocks executed (forward: coefficient rebuilds, backward: flushes), [5] lanes active in them, [6] wave-steps. */
+int md_costvol_stats(int enable, unsigned long long *out8);
 /* the individual durations, in launch order: fills us[0 .. min(n, cap)) and returns n (>= 0) */
 int md_kernel_timing_list(const char *name, double *us, int cap);
 

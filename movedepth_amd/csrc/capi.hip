@@ -23,6 +23,21 @@ bool g_timing = false;
 std::vector<TimingRec> g_recs;
 }  // namespace
 
+// Work counters of the channels-last plane-sweep kernels (diagnostics: how often windows are staged, taps miss them, cells
+// change).  8 x u64 in device memory, allocated on first enable.
+namespace { unsigned long long *g_stats = nullptr; bool g_stats_on = false; }
+unsigned long long *md_stats_buffer() { return g_stats_on ? g_stats : nullptr; }
+extern "C" int md_costvol_stats(int enable, unsigned long long *out8) {
+    if (enable && !g_stats) MD_CHECK_HIP(hipMalloc(&g_stats, 8 * sizeof(unsigned long long)));
+    if (out8 && g_stats) {
+        MD_CHECK_HIP(hipDeviceSynchronize());
+        MD_CHECK_HIP(hipMemcpy(out8, g_stats, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    }
+    if (g_stats) MD_CHECK_HIP(hipMemset(g_stats, 0, 8 * sizeof(unsigned long long)));
+    g_stats_on = enable != 0;
+    return MD_OK;
+}
+
 // A start / stop event pair for ONE kernel dispatch (hipExtLaunchKernelGGL ties them to the dispatch's own begin / end
 // timestamps -- the clock rocprofv3's kernel trace reads -- so host launch latency is not part of the interval); null, null
 // when timing is off.

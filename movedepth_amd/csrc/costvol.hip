@@ -94,7 +94,8 @@ struct CvDims {
     int B, C, G, h, w, D;
     int tiles_x, tiles, splits;  // pixel tiles per sample (x, total) and channel splits
     int items;                   // B * tiles * splits work items of D hypotheses each
-    int dbg;                     // tuning only (MD_CV_DBG): bit 0 skip LDS atomics, 1 skip window flush, 2 skip gradient loads
+    int dbg;                     // unused
+    unsigned long long *stats;   // md_costvol_stats: per-launch counters (null: off)
     long long sb, sd, sg, sp;
 };
 
@@ -745,7 +746,8 @@ int launch_cl(const CvPtrs &q, CvDims dm, hipStream_t stream) {
     dm.tiles = dm.tiles_x * md_cdiv(dm.h, NW);
     dm.splits = 1;
     dm.items = dm.B * dm.tiles;
-    dm.dbg = env_int("MD_CV_DBG", 0);
+    dm.dbg = 0;
+    dm.stats = md_stats_buffer();
 #define MD_CL_F(N_, LPP_)                                                                                        \
     do {                                                                                                         \
         if (NW == 4)                                                                                             \

@@ -36,6 +36,7 @@ void md_set_error(const char *fmt, ...);
         }                                                                     \
     } while (0)
 
+unsigned long long *md_stats_buffer();  // capi.hip: device counters for md_costvol_stats, null when off
 // kernel timing hook (capi.hip): start / stop events for hipExtLaunchKernelGGL, null unless md_kernel_timing_enable(1)
 void md_timing_pair(const char *name, hipEvent_t *start, hipEvent_t *stop);
 

@@ -35,7 +35,7 @@ def main():
     ap.add_argument("--fused", type=int, default=1)
     ap.add_argument("--layout", default="bgd")
     ap.add_argument("--iters", type=int, default=50)
-    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "f16"], help="feature-map and volume element type")
+    ap.add_argument("--dtype", default=os.environ.get("DT", "f32"), choices=["f32", "bf16", "f16"], help="feature-map and volume element type")
     ap.add_argument("--prior", default=os.environ.get("PRIOR", "white"), choices=["white", "smooth", "const"],
                     help="depth prior: white noise per pixel in [2,22) (adversarial: neighbouring pixels sweep unrelated epipolar "
                          "segments), a smooth field (what the mono decoder produces), or a constant")
@@ -110,6 +110,18 @@ def main():
     print("costvol B=%d %dx%d D=%d C=%d G=%d fused=%d layout=%s dtype=%s prior=%s env=%s" % (B, h, w, D, C, G, a.fused, a.layout, a.dtype, a.prior, env))
     print("  fwd %8.1f us  %7.1f MB  %7.0f GB/s (%.1f%% of 8 TB/s)" % (tf, fbytes / 1e6, fbytes / tf / 1e3, fbytes / tf / 1e3 / 80))
     print("  bwd %8.1f us  %7.1f MB  %7.0f GB/s (%.1f%% of 8 TB/s)  [includes 2 memsets + autograd glue]" % (tb, bbytes / 1e6, bbytes / tb / 1e3, bbytes / tb / 1e3 / 80))
+    if os.environ.get("MD_CV_STATS"):
+        import ctypes
+        from movedepth_amd import _lib
+        lib = _lib.load()
+        for nm, fn in (("fwd", fwd), ("bwd", bwd)):
+            lib.md_costvol_stats(1, None)
+            fn()
+            buf = (ctypes.c_ulonglong * 8)()
+            lib.md_costvol_stats(0, buf)
+            v = list(buf)
+            print("  stats %s: segments %d, windows staged %d, fit attempts %d, lanes redoing misses %d, cell-change blocks %d "
+                  "(%.1f lanes each), wave-steps %d" % (nm, v[0], v[1], v[2], v[3], v[4], v[5] / max(v[4], 1), v[6]))
     for k, v in lib_t.items():
         nb = fbytes if "fwd" in k else bbytes
         print("  kernel only (dispatch start/stop events inside the library) %-16s avg %7.1f us  min %7.1f us  %d launches  %.1f%% of 8 TB/s" % (

@@ -1,5 +1,8 @@
-for e in "X=0" "X=1" "X=2"; do
-echo "=== $e: $(env $e python bench.py --no_cpu_baseline 2>/dev/null | python -c "
-import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']; print(round(d['ms_per_step'],2), round(r['avg_launch_us'],1), round(r['bwd_avg_launch_us'],1), r.get('min_launch_us'))")"
-done
-rocm-smi --showclocks 2>/dev/null | head -20
+python -m pytest tests/test_hip_parity.py tests/test_baseline_configs.py -m gpu -q -k "costvol" 2>&1 | tail -1
+run() { echo "=== $*"; env "$@" MD_CV_STATS=1 python tools/bench_costvol.py --layout ndhwc --iters 10 2>&1 | grep -E "kernel only|stats" | cut -c1-200; }
+run2() { echo "=== cfg4 $*"; env "$@" MD_CV_STATS=1 python tools/bench_costvol.py --layout ndhwc --iters 10 --h 80 --w 256 --D 128 2>&1 | grep -E "kernel only|stats" | cut -c1-200; }
+run PRIOR=smooth
+run PRIOR=white
+run2 PRIOR=smooth DT=bf16
+run2 PRIOR=white DT=bf16
+MD_CV_STATS=1 MD_BENCH_DUMP_TIMES=1 python bench.py --steps 6 --warmup 4 --no_cpu_baseline --trainer_args="--res_arch 50 --height 320 --width 1024 --num_depth_bins 128 --amp bf16" 2>&1 >/dev/null | grep -E "costvol" | cut -c1-400
