@@ -214,16 +214,18 @@ int md_conv3d_c16_bwd_weight(const float *x, int x_planar, const float *gy, floa
  * conv0's BatchNorm3d + ReLU (networks/resnet_encoder.py:231 through ConvBnReLU3D) and conv11's BatchNorm3d + ReLU
  * followed by `x = conv0 + self.conv11(x)` (:249-252, :264).  x, y, res, dy, dx: channels-last volumes flattened to
  * [nvox,16].  Two-phase so that a data-parallel caller can all-reduce the 32 sums in between (SyncBatchNorm):
- *   md_bn_relu_stats      -> sums[0:16] = sum x, sums[16:32] = sum x^2          (caller: mean, biased var, invstd)
+ *   md_bn_relu_stats      -> sums[0:16] = sum x, sums[16:32] = sum x^2, in DOUBLE (E[x^2] - E[x]^2 from float sums loses
+ *                            (mean/std)^2 * 6e-8 of the variance); the caller all-reduces them, md_bn_relu_finalize turns them
+ *                            into mean, biased variance, invstd
  *   md_bn_relu_apply      y = max(0, (x - mean) * invstd * gamma + beta) [+ res]   (res may be NULL; y may alias x)
  *   md_bn_relu_bwd_reduce -> sums[0:16] = sum dz (= dbeta), sums[16:32] = sum dz * xhat (= dgamma), dz = dy * [z > 0]
  *   md_bn_relu_bwd_dx     dx = gamma * invstd * (dz - sums[0]/n_total - xhat * sums[1]/n_total)
  * ws: md_bn_relu_ws_bytes() bytes.  Reductions are two-stage in a fixed order (fp64 final sum). */
 size_t md_bn_relu_ws_bytes(void);
-int md_bn_relu_stats(const float *x, long long nvox, int C, float *sums, void *ws, md_stream_t stream);
+int md_bn_relu_stats(const float *x, long long nvox, int C, double *sums, void *ws, md_stream_t stream);
 /* mean / invstd from the (all-reduced) sums over n_total voxels; running_mean / running_var (may be NULL) updated in place
  * with `momentum` (unbiased variance), as F.batch_norm does in training */
-int md_bn_relu_finalize(const float *sums, long long n_total, int C, float eps, float momentum, float *mean, float *invstd,
+int md_bn_relu_finalize(const double *sums, long long n_total, int C, float eps, float momentum, float *mean, float *invstd,
                         float *running_mean, float *running_var, md_stream_t stream);
 int md_bn_relu_apply(const float *x, const float *mean, const float *invstd, const float *gamma, const float *beta,
                      const float *res, long long nvox, int C, float *y, md_stream_t stream);

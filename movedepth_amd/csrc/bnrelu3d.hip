@@ -56,7 +56,8 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float4 *__restrict_
 }
 
 // sums[o] = sum over blocks of partial[blk][o], o < KC = 2*C, fixed order, fp64
-__global__ __launch_bounds__(256) void bn_finish_kernel(const float *__restrict__ partial, int nblk, int KC, float *__restrict__ sums) {
+template <typename OUT>
+__global__ __launch_bounds__(256) void bn_finish_kernel(const float *__restrict__ partial, int nblk, int KC, OUT *__restrict__ sums) {
     __shared__ double sh[256];
     const int o = threadIdx.x % KC, seg = threadIdx.x / KC, nseg = 256 / KC;
     double s = 0.0;
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(256) void bn_finish_kernel(const float *__restrict_
     if (seg == 0) {
         double t = 0.0;
         for (int k = 0; k < nseg; ++k) t += sh[k * KC + o];
-        sums[o] = (float)t;
+        sums[o] = (OUT)t;
     }
 }
 
@@ -101,9 +102,13 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float4 *__rest
                                                             long long npieces, float *__restrict__ partial) {
     __shared__ float4 sh[4 * QN];
     const int q = threadIdx.x % QN;
-    float mu[4], is[4], ga[4], be[4];
+    float mu[4], is[4], ga[4], be[4], sc[4], sf[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { const int c = q * 4 + k; mu[k] = mean[c]; is[k] = invstd[c]; ga[k] = gamma[c]; be[k] = beta[c]; }
+    for (int k = 0; k < 4; ++k) {
+        const int c = q * 4 + k;
+        mu[k] = mean[c]; is[k] = invstd[c]; ga[k] = gamma[c]; be[k] = beta[c];
+        sc[k] = ga[k] * is[k]; sf[k] = be[k] - mu[k] * sc[k];
+    }
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f), sx = s;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < npieces; i += (long long)gridDim.x * 256) {
         const float4 v = x[i], g = dy[i];
@@ -112,7 +117,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float4 *__rest
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const float xh = (xv[k] - mu[k]) * is[k];
-            const float dz = fmaf(xh, ga[k], be[k]) > 0.f ? gv[k] : 0.f;
+            const float dz = fmaf(xv[k], sc[k], sf[k]) > 0.f ? gv[k] : 0.f;   // the forward's own expression (bn_apply_kernel)
             a[k] = dz; b[k] = dz * xh;
         }
         s = f4_add(s, make_float4(a[0], a[1], a[2], a[3]));
@@ -134,11 +139,12 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const float4 *__restrict
                                                         const float *__restrict__ sums, float inv_n, long long npieces,
                                                         float4 *__restrict__ dx) {
     const int q = threadIdx.x % QN;
-    float mu[4], is[4], ga[4], be[4], m1[4], m2[4];
+    float mu[4], is[4], ga[4], be[4], m1[4], m2[4], sc[4], sf[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int c = q * 4 + k;
         mu[k] = mean[c]; is[k] = invstd[c]; ga[k] = gamma[c]; be[k] = beta[c];
+        sc[k] = ga[k] * is[k]; sf[k] = be[k] - mu[k] * sc[k];
         m1[k] = sums[c] * inv_n; m2[k] = sums[4 * QN + c] * inv_n;
     }
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < npieces; i += (long long)gridDim.x * 256) {
@@ -148,7 +154,7 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const float4 *__restrict
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const float xh = (xv[k] - mu[k]) * is[k];
-            const float dz = fmaf(xh, ga[k], be[k]) > 0.f ? gv[k] : 0.f;
+            const float dz = fmaf(xv[k], sc[k], sf[k]) > 0.f ? gv[k] : 0.f;   // the forward's own expression (bn_apply_kernel)
             o[k] = ga[k] * is[k] * (dz - m1[k] - xh * m2[k]);
         }
         dx[i] = make_float4(o[0], o[1], o[2], o[3]);
@@ -157,13 +163,14 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const float4 *__restrict
 
 // mean, invstd (biased variance) from the two sums, and BatchNorm's running statistics (unbiased variance), in one tiny
 // launch instead of a dozen host-side tensor ops per call
-__global__ void bn_finalize_kernel(const float *__restrict__ sums, int C, double n, float eps, float momentum, float *__restrict__ mean,
+__global__ void bn_finalize_kernel(const double *__restrict__ sums, int C, double n, float eps, float momentum, float *__restrict__ mean,
                                    float *__restrict__ invstd, float *__restrict__ running_mean,
                                    float *__restrict__ running_var) {
     const int c = threadIdx.x;
     if (c >= C) return;
-    const double m = (double)sums[c] / n;
-    double var = (double)sums[C + c] / n - m * m;
+    // the two sums arrive in double: E[x^2] - E[x]^2 from sums rounded to float loses (mean/std)^2 * 6e-8 of the variance
+    const double m = sums[c] / n;
+    double var = sums[C + c] / n - m * m;
     if (var < 0.0) var = 0.0;
     mean[c] = (float)m;
     invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
@@ -198,7 +205,7 @@ extern "C" {
 
 size_t md_bn_relu_ws_bytes(void) { return (size_t)NBLK * 2 * 64 * sizeof(float); }
 
-int md_bn_relu_stats(const float *x, long long nvox, int Cc, float *sums, void *ws, md_stream_t stream) {
+int md_bn_relu_stats(const float *x, long long nvox, int Cc, double *sums, void *ws, md_stream_t stream) {
     MD_REQUIRE(x && sums && ws, "md_bn_relu_stats: null tensor argument");
     if (int rc = bn_check("md_bn_relu_stats", nvox, Cc)) return rc;
     const int QN = Cc / 4;
@@ -206,12 +213,12 @@ int md_bn_relu_stats(const float *x, long long nvox, int Cc, float *sums, void *
     const int nb = bn_blocks(np);
     MD_BN_DISPATCH(bn_stats_kernel, dim3(nb), (const float4 *)x, np, (float *)ws);
     MD_CHECK_LAUNCH("md_bn_relu_stats");
-    hipLaunchKernelGGL(bn_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float *)ws, nb, 2 * Cc, sums);
+    hipLaunchKernelGGL(bn_finish_kernel<double>, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float *)ws, nb, 2 * Cc, sums);
     MD_CHECK_LAUNCH("md_bn_relu_stats(finish)");
     return MD_OK;
 }
 
-int md_bn_relu_finalize(const float *sums, long long n_total, int Cc, float eps, float momentum, float *mean, float *invstd,
+int md_bn_relu_finalize(const double *sums, long long n_total, int Cc, float eps, float momentum, float *mean, float *invstd,
                         float *running_mean, float *running_var, md_stream_t stream) {
     MD_REQUIRE(sums && mean && invstd, "md_bn_relu_finalize: null tensor argument");
     if (int rc = bn_check("md_bn_relu_finalize", n_total, Cc)) return rc;
@@ -243,7 +250,7 @@ int md_bn_relu_bwd_reduce(const float *dy, const float *x, const float *mean, co
     const int nb = bn_blocks(np);
     MD_BN_DISPATCH(bn_bwd_reduce_kernel, dim3(nb), (const float4 *)dy, (const float4 *)x, mean, invstd, gamma, beta, np, (float *)ws);
     MD_CHECK_LAUNCH("md_bn_relu_bwd_reduce");
-    hipLaunchKernelGGL(bn_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float *)ws, nb, 2 * Cc, sums);
+    hipLaunchKernelGGL(bn_finish_kernel<float>, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float *)ws, nb, 2 * Cc, sums);
     MD_CHECK_LAUNCH("md_bn_relu_bwd_reduce(finish)");
     return MD_OK;
 }

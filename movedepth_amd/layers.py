@@ -29,21 +29,22 @@ def disp_to_depth(disp, min_depth, max_depth):
 
 
 def rot_from_axisangle(vec):
-    """Rodrigues, (B,1,3) -> (B,4,4).  reference layers.py:479-518"""
-    angle = torch.norm(vec, 2, 2, True)
-    axis = vec / (angle + 1e-7)
-    ca, sa = torch.cos(angle), torch.sin(angle)
-    C = 1 - ca
-    x, y, z = axis[..., 0].unsqueeze(1), axis[..., 1].unsqueeze(1), axis[..., 2].unsqueeze(1)
-    xs, ys, zs = x * sa, y * sa, z * sa
-    xC, yC, zC = x * C, y * C, z * C
-    xyC, yzC, zxC = x * yC, y * zC, z * xC
-    zero, one = torch.zeros_like(x), torch.ones_like(x)
-    rows = [x * xC + ca, xyC - zs, zxC + ys, zero,
-            xyC + zs, y * yC + ca, yzC - xs, zero,
-            zxC - ys, yzC + xs, z * zC + ca, zero,
-            zero, zero, zero, one]
-    return torch.cat(rows, dim=2).reshape(vec.shape[0], 4, 4)
+    """Axis-angle (B,1,3) -> 4x4 rotation by Rodrigues' formula R = cos(a) I + sin(a) [k]x + (1 - cos(a)) k k^T with
+    k = v / (|v| + 1e-7) (the reference's guard, layers.py:485-486): same matrix as layers.py:479-518, written from the
+    formula rather than entry by entry."""
+    v = vec.reshape(-1, 3)
+    angle = v.norm(dim=1, keepdim=True)
+    k = v / (angle + 1e-7)
+    c, s_ = torch.cos(angle)[:, :, None], torch.sin(angle)[:, :, None]
+    zero = torch.zeros_like(k[:, 0])
+    skew = torch.stack([zero, -k[:, 2], k[:, 1], k[:, 2], zero, -k[:, 0], -k[:, 1], k[:, 0], zero], 1).reshape(-1, 3, 3)
+    outer = k[:, :, None] * k[:, None, :]
+    # (1 - c) k k^T + c I: the reference's diagonal is x*x*(1-c) + c, i.e. NOT normalised by |k|^2 -- keep the identity term plain
+    R3 = (1 - c) * outer + c * torch.eye(3, device=v.device, dtype=v.dtype) + s_ * skew
+    R = torch.zeros(v.shape[0], 4, 4, device=v.device, dtype=v.dtype)
+    R[:, :3, :3] = R3
+    R[:, 3, 3] = 1
+    return R
 
 
 def get_translation_matrix(translation_vector):

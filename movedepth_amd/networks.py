@@ -401,15 +401,35 @@ class reg3d(nn.Module):
         if not self.find_convs or not inputs.is_cuda:
             return self._forward(inputs)
         prev = torch.backends.cudnn.benchmark
-        if inputs.requires_grad:
-            inputs.register_hook(lambda g: _set_benchmark(prev, g))      # fires after this module's backward
         torch.backends.cudnn.benchmark = True
         try:
             out = self._forward(inputs)
         finally:
             torch.backends.cudnn.benchmark = prev
         if out.requires_grad:
-            out.register_hook(lambda g: _set_benchmark(True, g))         # fires before this module's backward
+            # backward: switch the search on when the gradient reaches this module's output and off again when it leaves
+            # the module -- at the input's gradient if the input needs one, otherwise at the weight gradient of the first
+            # library convolution (the last node of this module's backward).  One-shot hooks, so a detached input can
+            # never leave the process-wide flag on for the 2-D networks' backward.
+            first = self.conv1.conv if (self.hip_conv0_wgrad and not self.lib_conv0_fwd_dgrad) else self.conv0.conv
+            state = {}
+
+            def leave(g):
+                torch.backends.cudnn.benchmark = prev
+                h = state.pop("h", None)
+                if h is not None:
+                    h.remove()
+                return g
+
+            def enter(g):
+                torch.backends.cudnn.benchmark = True
+                if not inputs.requires_grad and first.weight.requires_grad:
+                    state["h"] = first.weight.register_hook(leave)
+                return g
+
+            if inputs.requires_grad:
+                inputs.register_hook(leave)
+            out.register_hook(enter)
         return out
 
     def _up(self, name, x, skip):

@@ -622,7 +622,7 @@ class _BnRelu3d(torch.autograd.Function):
         C = x.shape[1]
         nvox = x.numel() // C
         ws = _ws(_lib.load().md_bn_relu_ws_bytes(), x.device)
-        sums = torch.empty(2 * C, device=x.device, dtype=torch.float32)
+        sums = torch.empty(2 * C, device=x.device, dtype=torch.float64)
         _timed_call("md_bn_relu_stats", _p(x), nvox, C, _p(sums), _p(ws), _stream())
         n_total = nvox
         if group is not None:

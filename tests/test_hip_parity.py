@@ -187,8 +187,9 @@ def test_warp_golden(ops, tag):
     assert_close(host(out), g["warped"])
     assert (host(mask).astype(bool) != g["mvs_mask"]).mean() < 2e-3
     (out * dev(g["grad_out"])).sum().backward()
-    assert_close(host(depth.grad), g["d_depth"], rtol=2e-4, atol_scale=5e-3, what="d_depth")
-    assert_close(host(T.grad), g["d_T"], rtol=2e-4, what="d_T")
+    print("warp golden", tag, "d_depth", relerr(host(depth.grad), g["d_depth"]), "d_T", relerr(host(T.grad), g["d_T"]))
+    assert_close(host(depth.grad), g["d_depth"], rtol=1e-4, atol_scale=5e-3, what="d_depth")
+    assert_close(host(T.grad), g["d_T"], rtol=1e-4, what="d_T")
 
 
 def test_warp_vs_oracle_fullres(ops, oracle_lib):
@@ -211,7 +212,48 @@ def test_warp_vs_oracle_fullres(ops, oracle_lib):
     assert_close_knife_edge(host(d.grad).reshape(exp_dd.shape), exp_dd, rtol=2e-4, what="d_depth")
     # d_T sums 122,880 per-pixel terms that cancel to ~1% of their absolute sum; the per-block partial sums are
     # fp32 (as is the reference's sgemm over the same axis), the oracle accumulates in fp64
+    print("warp fullres d_T rel err", relerr(host(t.grad), exp_dT))
     assert_close(host(t.grad), exp_dT, rtol=1e-3, what="d_T")
+    # Why 1e-3 and not 1e-4 above: two float32 implementations place a handful of the 245,760 samples in different texels
+    # (positions within rounding of a texel boundary), each such sample changes its term by O(1), and the terms cancel to ~1 %
+    # of their absolute sum.  Shown here: the same sum evaluated in float64 AT THE KERNEL'S OWN sample positions (so with its
+    # texel decisions) agrees with the kernel to north_star's 1e-4 (measured 6.4e-5, of which the float32 rounding of the
+    # positions handed to this check is a part) -- 93 % of the distance to the oracle is texel decisions, not arithmetic.
+    assert_close(host(t.grad), _warp_dT_float64(img, depth, K, invK, T, gout, host(pix)), rtol=1e-4, what="d_T at own positions")
+
+
+def _warp_dT_float64(img, depth, K, invK, T, gout, pix):
+    """dL/dT of grid_sample(img, pix, border, align_corners=True) with pix = Project3D(BackprojectDepth(depth)) (reference
+    layers.py:556-621, autograd of trainer.py:519-529), in float64, taking the sampled texel of every pixel from `pix`."""
+    B, Ci, H, W = img.shape
+    img, gout, depth = img.astype(np.float64), gout.astype(np.float64), depth.astype(np.float64).reshape(B, H, W)
+    ys, xs = np.meshgrid(np.arange(H, dtype=np.float64), np.arange(W, dtype=np.float64), indexing="ij")
+    out = np.zeros((B, 4, 4))
+    for b in range(B):
+        Kb, iKb, Tb = K[b].astype(np.float64), invK[b].astype(np.float64), T[b].astype(np.float64)
+        ray = np.einsum("ij,jhw->ihw", iKb[:3, :3], np.stack([xs, ys, np.ones_like(xs)]))
+        Xh = np.concatenate([ray * depth[b][None], np.ones((1, H, W))], 0)                      # (4,H,W)
+        P = (Kb @ Tb)[:3]
+        zz = np.einsum("j,jhw->hw", P[2], Xh) + 1e-7
+        ix = (pix[b, ..., 0].astype(np.float64) + 1) / 2 * (W - 1)                                # the kernel's positions
+        iy = (pix[b, ..., 1].astype(np.float64) + 1) / 2 * (H - 1)
+        inx, iny = (ix >= 0) & (ix <= W - 1), (iy >= 0) & (iy <= H - 1)                           # border: clamped => zero grid gradient
+        cx, cy = np.clip(ix, 0, W - 1), np.clip(iy, 0, H - 1)
+        x0, y0 = np.minimum(np.floor(cx), W - 1).astype(int), np.minimum(np.floor(cy), H - 1).astype(int)
+        wx1, wy1 = cx - x0, cy - y0
+        x1, y1 = np.minimum(x0 + 1, W - 1), np.minimum(y0 + 1, H - 1)
+        vx1, vy1 = (x0 + 1 < W), (y0 + 1 < H)
+        gix, giy = np.zeros((H, W)), np.zeros((H, W))
+        for c in range(Ci):
+            im = img[b, c]
+            nw, ne, sw, se = im[y0, x0], np.where(vx1, im[y0, x1], 0), np.where(vy1, im[y1, x0], 0), np.where(vx1 & vy1, im[y1, x1], 0)
+            gix += gout[b, c] * ((ne - nw) * (1 - wy1) + (se - sw) * wy1)
+            giy += gout[b, c] * ((sw - nw) * (1 - wx1) + (se - ne) * wx1)
+        du, dv = gix * inx, giy * iny                      # d(ix)/du = 1: the [-1,1] normalise / un-normalise factors cancel
+        dc = np.stack([du / zz, dv / zz, -(du * ix + dv * iy) / zz])                               # u = ix, v = iy where unclamped
+        dP = np.einsum("ihw,jhw->ij", dc, Xh)                                                      # (3,4)
+        out[b] = Kb[:3].T @ dP
+    return out.astype(np.float32)
 
 
 @pytest.mark.parametrize("hw", [(4, 8), (8, 16), (16, 32), (32, 64)])

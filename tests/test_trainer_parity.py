@@ -73,11 +73,15 @@ def test_mono_losses_match_reference():
     assert_close(host(outputs["mono_reproj_loss"]), g["mono_reproj_loss"])
     losses["loss"].backward()
     for s in range(4):
-        assert_close_knife_edge(host(disps[s].grad), g["d_disp_%d" % s], rtol=5e-4, max_outlier_frac=5e-3,
-                                what="d_disp_%d" % s)
+        assert_close(host(disps[s].grad), g["d_disp_%d" % s], rtol=1e-4, atol_scale=1e-2, what="d_disp_%d" % s)
     for f, n in ((-1, "m1"), (1, "p1")):
-        assert_close(host(aa[f].grad), g["d_axisangle_" + n], rtol=2e-3, what="d_axisangle")
-        assert_close(host(tr[f].grad), g["d_translation_" + n], rtol=2e-3, what="d_translation")
+        print("pose gradient rel err", n, relerr(host(aa[f].grad), g["d_axisangle_" + n]), relerr(host(tr[f].grad), g["d_translation_" + n]),
+              "reference fp32-vs-fp64:", float(g["noise_d_axisangle_" + n]), float(g["noise_d_translation_" + n]))
+        # bound: north_star's 1e-4 (measured 1e-6; the reference's own float32 gradients sit 2.4e-6 from float64 ones)
+        assert_close(host(aa[f].grad), g["d_axisangle_" + n], rtol=1e-4, what="d_axisangle")
+        assert_close(host(tr[f].grad), g["d_translation_" + n], rtol=1e-4, what="d_translation")
+    for s in range(4):
+        print("d_disp rel err", s, relerr(host(disps[s].grad), g["d_disp_%d" % s]), "reference fp32-vs-fp64:", float(g["noise_d_disp_%d" % s]))
 
 
 def test_mono_losses_without_automask():
@@ -116,8 +120,9 @@ def test_mvs_and_fuse_losses_match_reference(tag, flags):
     if "mvs_smooth_loss" in g:
         assert abs(float(mvs_losses["mvs_smooth_loss/0"]) - float(g["mvs_smooth_loss"])) < 1e-4 * float(g["mvs_smooth_loss"])
     (mvs_losses["loss"] + fuse_losses["loss"]).backward()
-    assert_close_knife_edge(host(depth_mvs.grad), g["d_depth_mvs"], rtol=5e-4, max_outlier_frac=5e-3, what="d_depth_mvs")
-    assert_close_knife_edge(host(trust.grad), g["d_trust"], rtol=5e-4, max_outlier_frac=5e-3, what="d_trust")
+    print("d_depth_mvs / d_trust rel err", relerr(host(depth_mvs.grad), g["d_depth_mvs"]), relerr(host(trust.grad), g["d_trust"]))
+    assert_close_knife_edge(host(depth_mvs.grad), g["d_depth_mvs"], rtol=1e-4, max_outlier_frac=2e-3, what="d_depth_mvs")
+    assert_close_knife_edge(host(trust.grad), g["d_trust"], rtol=1e-4, max_outlier_frac=2e-3, what="d_trust")
 
 
 def test_process_batch_runs_and_has_reference_keys():
