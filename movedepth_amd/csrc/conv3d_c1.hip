@@ -21,7 +21,25 @@
 //   bwd-weight ends with a shuffle reduction over the lanes of equal quad, an LDS reduction over the 4 waves, one
 //   partial [27*C] per workgroup in the caller's workspace and a second kernel that adds the partials in a fixed
 //   order (deterministic; no float atomics).
+//
+// Second generation, C = 16 (what the trainer runs; the kernels above remain for C = 8 and irregular weight strides):
+//   fwd:        lane = voxel (all 16 channels), so the weights are WAVE-UNIFORM and live in SGPRs (scalar loads, v_fma with a
+//               scalar operand): no weight registers, no weight LDS traffic, no cross-lane sums.  16x32 tile, x plane staged
+//               planar per channel quad ([quad][cell] float4, conflict-free row reads); a thread owns two vertically adjacent
+//               voxels and reads 4 rows x 3 columns x 4 quads per plane (24 b128 per voxel against 63 before).
+//   bwd-data:   MFMA (v_mfma_f32_16x16x4_f32, exact fp32): D[c][voxel] += A[c][tap] * B[tap][voxel], 7 K-steps over the 27 (+1
+//               zero) taps; A = weights (7 registers), B = gy gathered from the LDS ring (one ds_read_b32 per MFMA); a lane's
+//               4 results are channels 4q..4q+3 of one voxel = one coalesced float4 store (1 KB per wave).
+//   bwd-weight: MFMA: D[tap][c] += A[tap][voxel] * B[voxel][c]; B = x as ONE DWORD PER LANE in memory order (4 voxels x 16
+//               channels = 256 contiguous bytes, global -> register -> MFMA), A = gy from the LDS ring, two M tiles (taps 0-15,
+//               16-26); per 4 voxels: 1 global load, 2 LDS reads, 2 MFMAs, no VALU arithmetic.
+#include <type_traits>
+
 #include "md_common.hpp"
+
+#ifndef MD_C1_PROBE_BW
+#define MD_C1_PROBE_BW 0  // timing experiments on the weight-gradient kernel (1: no gy fetch in the march, 2: no MFMAs); wrong results
+#endif
 
 namespace {
 
@@ -331,6 +349,343 @@ __global__ __launch_bounds__(256) void conv3d_c1_bwd_weight_finish_kernel(const 
     if (threadIdx.x == 0) dwt[(o / C) * dsk + (o % C) * dsc] = (float)sh[0];
 }
 
+// ================================================================================================ second generation, C = 16
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// The MFMA kernels run WITHOUT workgroup barriers: each wave owns two tile rows (64 voxels) and keeps its own ring of three gy
+// planes (its 2 rows + 1 halo row above and below, 34 columns) in LDS.  A wave's LDS operations execute in program order, so
+// the wave that wrote a slot can read it back without s_barrier, and the four waves of a workgroup drift apart freely (a
+// barrier per plane kept the memory pipeline in lock-step: 70-77 us against 52 us for the bare access pattern,
+// tools/micro/c1_load_probe.hip).  gy is 1/16 of the traffic; the doubled halo rows come from L2.
+//   RP = row pitch, SP = slot pitch (floats), chosen per kernel so that the operand gathers are bank-conflict-free.
+template <int RP, int SP, int NS = 3>
+struct WaveRing {
+    static constexpr int ROWS = 4, COLS = HW_, N = ROWS * COLS;  // 136 values per plane
+    static constexpr int NLD = (N + 63) / 64;
+    static_assert(SP >= ((NLD * 64 - 1) / COLS) * RP + COLS, "a slot holds every lane's piece");
+    float *base;   // this wave's NS slots
+    int lofs[NLD];  // global offset inside a plane, -1 = zero (outside the image / beyond N)
+    int sofs[NLD];  // slot-relative LDS offset
+    float r[NLD];
+
+    __device__ __forceinline__ void init(float *lds, const C1Dims &dm, int ty0, int tx0, int wave, int lane) {
+        base = lds + wave * NS * SP;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int idx = lane + 64 * i, row = idx / COLS, col = idx % COLS;
+            const int yy = ty0 + 2 * wave - 1 + row, xx = tx0 - 1 + col;
+            lofs[i] = (idx < N && yy >= 0 && yy < dm.H && xx >= 0 && xx < dm.W) ? yy * dm.W + xx : -1;
+            sofs[i] = row * RP + col;  // idx >= N: rows 4, 5 of the slot, never read (no store under a branch)
+        }
+    }
+    __device__ __forceinline__ int slot(int P) const { return (NS == 4 ? ((P + 4) & 3) : (P + 3) % 3) * SP; }
+    // Unconditional loads from a clamped address, zeroed when they are consumed (stash): a load under a branch makes the
+    // compiler wait for vmcnt(0) -- every store in flight included -- where it could count (measured: the data gradient
+    // waited for its own stores at every step), and a select right after the load would wait for it on the spot.
+    bool rin;
+    __device__ __forceinline__ void fetch(const float *__restrict__ gyb, const C1Dims &dm, int P) {
+        rin = P >= 0 && P < dm.D;
+        const float *pl = gyb + (size_t)min(max(P, 0), dm.D - 1) * dm.H * dm.W;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) r[i] = pl[max(lofs[i], 0)];
+    }
+    __device__ __forceinline__ void stash(int P) {
+        float *s = base + slot(P);
+#pragma unroll
+        for (int i = 0; i < NLD; ++i)
+            s[sofs[i]] = (rin && lofs[i] >= 0) ? r[i] : 0.f;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+};
+
+// ------------------------------------------------------------------------------------------------ backward (data), MFMA
+// Group = 16 consecutive voxels of a tile row.  Lane (n = lane & 15, kq = lane >> 4): A holds w[tap 4kk+kq][channel n],
+// B holds gy at voxel n displaced by tap 4kk+kq, D holds dx[voxel n][channels 4kq .. 4kq+3].
+//
+// gy of the WHOLE slice (planes d0-1 .. d1, tile + halo: (planes + 2) x 10 x 34 floats, 22 KB for 12 planes) is loaded into
+// LDS before the first step; the march itself issues no loads.  Why: the kernel is a 283 MB store stream, and a load issued
+// into it comes back late (the memory system is busy writing): with gy fetched one plane ahead every step waited for its
+// fetch -- 69 us, against 50.6 us with the fetch removed and 53 us for the bare store pattern (tools/micro/c1_load_probe.hip).
+// (Two other suspects were cleared first, at no gain: the per-plane workgroup barrier, and a vmcnt(0) that made each step wait
+// for its own stores -- loads under branches and a loop-carried prefetch register defeat the compiler's exact vmcnt counting.)
+constexpr int BD_RP = 40, BD_PS = HH_ * BD_RP;  // row pitch, plane pitch (floats) of the staged gy
+constexpr int BD_MAX_PLANES = 16;
+
+__global__ __launch_bounds__(256) void conv3d_c1_bwd_data_mfma_kernel(const float *__restrict__ gy, const float *__restrict__ wt,
+                                                                      long long wsk, long long wsc, float *__restrict__ dx,
+                                                                      const C1Dims dm) {
+    extern __shared__ float lds[];  // [(d1 - d0 + 2)][HH_][BD_RP]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, kq = lane >> 4;
+    int b, ty0, tx0, d0, d1;
+    c1_item(dm, blockIdx.x, b, ty0, tx0, d0, d1);
+    if (d0 >= d1) return;
+    const size_t plane = (size_t)dm.H * dm.W;
+    const float *gyb = gy + (size_t)b * dm.D * plane;
+    {  // stage: 4 values in flight per thread and round
+        const int total = (d1 - d0 + 2) * CELLS;
+        for (int i0 = tid; i0 < total; i0 += 4 * 256) {
+            float v[4];
+            int so[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * 256, p = i / CELLS, cell = i - p * CELLS, row = cell / HW_, col = cell - row * HW_;
+                const int P = d0 - 1 + p, yy = ty0 - 1 + row, xx = tx0 - 1 + col;
+                const bool ok = i < total && P >= 0 && P < dm.D && yy >= 0 && yy < dm.H && xx >= 0 && xx < dm.W;
+                v[u] = ok ? gyb[(size_t)P * plane + (size_t)yy * dm.W + xx] : 0.f;
+                so[u] = i < total ? p * BD_PS + row * BD_RP + col : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (so[u] >= 0) lds[so[u]] = v[u];
+        }
+    }
+    float a[7];
+    int tofs[7];
+#pragma unroll
+    for (int kk = 0; kk < 7; ++kk) {
+        const int tap = 4 * kk + kq, t = tap < 27 ? tap : 0, kd = t / 9, kh = (t / 3) % 3, kw = t % 3;
+        a[kk] = tap < 27 ? wt[t * wsk + n * wsc] : 0.f;
+        // output (d, row, col) takes gy(d - kd + 1, row - kh + 1, col - kw + 1): staged plane (d - d0) + 2 - kd, row + 2 - kh, ..
+        tofs[kk] = (2 - kd) * BD_PS + (2 - kh) * BD_RP + 2 - kw + n;
+    }
+    float4 *dxb = reinterpret_cast<float4 *>(dx) + (size_t)b * dm.D * plane * 4;
+    // this wave's 4 groups: tile rows 2*wave, 2*wave + 1, column halves 0 / 16
+    int goff[4], vofs[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = 2 * wave + (i >> 1), c0 = (i & 1) * 16, yy = ty0 + row, xx = tx0 + c0 + n;
+        goff[i] = row * BD_RP + c0;
+        vofs[i] = (yy < dm.H && xx < dm.W) ? (yy * dm.W + xx) * 4 + kq : -1;
+    }
+    __syncthreads();  // the only barrier
+    for (int d = d0; d < d1; ++d) {
+        const float *pl = lds + (d - d0) * BD_PS;
+        f32x4 acc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < 7; ++kk) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kk], pl[tofs[kk] + goff[i]], acc[i], 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (vofs[i] >= 0) dxb[(size_t)d * plane * 4 + vofs[i]] = make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ backward (weight), MFMA
+// Group = 4 consecutive voxels of a tile row.  Lane (m = lane & 15, k = lane >> 4): B holds x[voxel k][channel m] (memory
+// order), A holds gy at voxel k displaced by tap m (tile 0) / tap 16+m (tile 1), D holds dwt[tap 16t + 4k + r][channel m].
+template <bool RAGGED>
+__global__ __launch_bounds__(256) void conv3d_c1_bwd_weight_mfma_kernel(const float *__restrict__ x, const float *__restrict__ gy,
+                                                                        float *__restrict__ partial, const C1Dims dm) {
+    // the 16 taps x 4 voxels of an A gather touch 9 (kd, kh) bases x 6 consecutive floats: bases 0, 6, .. 48 mod 64
+    constexpr int RP = 70, SP = 466;  // 70 = 6, 466 = 18 (mod 64); 6 rows of 70 fit
+    typedef WaveRing<RP, SP> Ring;
+    __shared__ float lds[4 * 3 * SP];
+    float(*red)[8][64] = reinterpret_cast<float(*)[8][64]>(lds);  // [4][8][64], after the march
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m = lane & 15, k = lane >> 4;
+    int b, ty0, tx0, d0, d1;
+    c1_item(dm, blockIdx.x, b, ty0, tx0, d0, d1);
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    if (d0 < d1) {
+        const int tA = m, tB = 16 + m;
+        const bool vB = tB < 27;
+        const int tBc = vB ? tB : 0;
+        const int kdA = tA / 9, offA = (2 - (tA / 3) % 3) * RP + 2 - tA % 3 + k;
+        const int kdB = tBc / 9, offB = (2 - (tBc / 3) % 3) * RP + 2 - tBc % 3 + k;
+        const size_t plane = (size_t)dm.H * dm.W;
+        const float *gyb = gy + (size_t)b * dm.D * plane;
+        const float *xb = x + (size_t)b * dm.D * plane * 16;
+        // this wave's 16 groups: tile rows 2*wave + (g >> 3), columns (g & 7) * 4 + k
+        const int xbase = ((ty0 + 2 * wave) * dm.W + tx0 + k) * 16 + m, xrow = dm.W * 16;
+        auto xok = [&](int g) -> bool { return !RAGGED || (ty0 + 2 * wave + (g >> 3) < dm.H && tx0 + (g & 7) * 4 + k < dm.W); };
+        auto xload = [&](int d, int g) -> float {  // raw: masked by xok when it is consumed
+            const float *p0 = xb + (size_t)d * plane * 16 + xbase;  // two row pointers + immediate offsets when not ragged
+            if (!RAGGED) return (g < 8 ? p0 : p0 + xrow)[(g & 7) * 64];
+            return p0[xok(g) ? (g >> 3) * xrow + (g & 7) * 64 : 0];
+        };
+        Ring R;
+        R.init(lds, dm, ty0, tx0, wave, lane);
+        R.fetch(gyb, dm, d0 - 1); R.stash(d0 - 1);
+        R.fetch(gyb, dm, d0);     R.stash(d0);
+        R.fetch(gyb, dm, d0 + 1);
+        // x one plane ahead of the MFMAs that consume it, in two register sets that swap roles (a copy at the top of the step
+        // lets the compiler rotate it into the previous step, where it waits for loads that were only just issued)
+        float xa[16], xb2[16];
+#pragma unroll
+        for (int g = 0; g < 16; ++g) xa[g] = xload(d0, g);
+        auto step = [&](int d, float (&cur)[16], float (&nxt)[16]) {
+#if MD_C1_PROBE_BW != 1
+            R.stash(d + 1);
+            R.fetch(gyb, dm, d + 2);  // unconditional, like the x loads below (clamped plane, unused after the last step)
+#endif
+            if (d + 1 < d1) {  // a branch is harmless here: the kernel has no stores in flight, the next wait is vmcnt(0) anyway
+#pragma unroll
+                for (int g = 0; g < 16; ++g) nxt[g] = xload(d + 1, g);
+            }
+            // Without this the scheduler sinks the 16 loads below the MFMAs and the wait for them follows at once: no
+            // prefetch distance at all (measured 74-81 us, 71 us even with the MFMAs replaced by single FMAs).
+            __builtin_amdgcn_sched_barrier(0);
+            const int s0 = R.slot(d + 1), s1 = R.slot(d), s2 = R.slot(d - 1);
+            const float *pA = R.base + (kdA == 0 ? s0 : kdA == 1 ? s1 : s2) + offA;
+            const float *pB = R.base + (kdB == 0 ? s0 : kdB == 1 ? s1 : s2) + offB;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const int go = (g >> 3) * RP + (g & 7) * 4;
+                const float a0 = pA[go];
+                float a1 = pB[go];
+                a1 = vB ? a1 : 0.f;
+                const float xv = xok(g) ? cur[g] : 0.f;
+#if MD_C1_PROBE_BW == 2
+                acc0[g & 3] = fmaf(a0, xv, acc0[g & 3]);
+                acc1[g & 3] = fmaf(a1, xv, acc1[g & 3]);
+#else
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, xv, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, xv, acc1, 0, 0, 0);
+#endif
+            }
+            __builtin_amdgcn_sched_barrier(0);  // the next step's loads stay behind this step's MFMAs
+        };
+        for (int d = d0; d < d1; d += 2) {
+            step(d, xa, xb2);
+            if (d + 1 < d1) step(d + 1, xb2, xa);
+        }
+    }
+    // the 4 waves meet in LDS; thread o sums dwt[tap o / 16][channel o % 16] and writes the workgroup's partial
+    __syncthreads();  // every wave is done with its ring
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        red[wave][rr][lane] = acc0[rr];
+        red[wave][4 + rr][lane] = acc1[rr];
+    }
+    __syncthreads();
+    for (int o = tid; o < 27 * 16; o += 256) {
+        const int tap = o >> 4, c = o & 15, t = tap >> 4, tr = tap & 15, sl = (tr >> 2) * 16 + c, rg = t * 4 + (tr & 3);
+        partial[(size_t)blockIdx.x * 27 * 16 + o] = (red[0][rg][sl] + red[1][rg][sl]) + (red[2][rg][sl] + red[3][rg][sl]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ forward, scalar weights
+namespace fw {
+constexpr int FTH = 16, FTW = 32, FHW = FTW + 2, FHH = FTH + 2, FCELLS = FHH * FHW;  // 612 cells
+constexpr int PITCH = FCELLS;                                                   // 612 % 16 == 4: staging writes spread over the banks
+constexpr int FNLD = (FCELLS * 4 + 255) / 256;
+static_assert(PITCH % 16 == 4, "quad planes must sit 4 slots apart");
+}  // namespace fw
+
+// WL = 0: weight in channels-last order (tap stride 16, channel stride 1); WL = 1: planar (tap stride 1, channel stride 27).
+template <int WL>
+__global__ __launch_bounds__(256) void conv3d_c1_fwd16_kernel(const float *__restrict__ x, const float *__restrict__ wt,
+                                                              float *__restrict__ y, const C1Dims dm) {
+    __shared__ float4 tile[4 * fw::PITCH];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int col = lane & 31, r0 = wave * 4 + (lane >> 5) * 2;  // output voxels (r0, col) and (r0 + 1, col) of the tile
+    int b, ty0, tx0, d0, d1;
+    {
+        const int item = blockIdx.x, sl = item % dm.dslices, t = (item / dm.dslices) % dm.tiles;
+        b = item / (dm.dslices * dm.tiles);
+        tx0 = (t % dm.tiles_x) * fw::FTW;
+        ty0 = (t / dm.tiles_x) * fw::FTH;
+        d0 = sl * dm.planes;
+        d1 = min(d0 + dm.planes, dm.D);
+    }
+    if (d0 >= d1) return;
+    const size_t plane = (size_t)dm.H * dm.W;
+    const float4 *xb = reinterpret_cast<const float4 *>(x) + (size_t)b * dm.D * plane * 4;
+    int lofs[fw::FNLD], sofs[fw::FNLD];  // global float4 offset inside a plane (-1: zero), LDS slot
+#pragma unroll
+    for (int i = 0; i < fw::FNLD; ++i) {
+        const int idx = tid + i * 256, cell = idx >> 2, qq = idx & 3;
+        const int yy = ty0 - 1 + cell / fw::FHW, xx = tx0 - 1 + cell % fw::FHW;
+        lofs[i] = (idx < fw::FCELLS * 4 && yy >= 0 && yy < dm.H && xx >= 0 && xx < dm.W) ? (yy * dm.W + xx) * 4 + qq : -1;
+        sofs[i] = idx < fw::FCELLS * 4 ? qq * fw::PITCH + cell : -1;
+    }
+    const int p0 = max(d0 - 1, 0), p1 = min(d1 + 1, dm.D);
+    float4 pre[fw::FNLD];
+    auto fetch = [&](int p) {
+#pragma unroll
+        for (int i = 0; i < fw::FNLD; ++i)
+            pre[i] = lofs[i] >= 0 ? xb[(size_t)p * plane * 4 + lofs[i]] : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    fetch(p0);
+    float acc[2][3][2];  // [voxel][kd][even / odd channel chain]
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int kd = 0; kd < 3; ++kd) acc[j][kd][0] = acc[j][kd][1] = 0.f;
+    const int gy0 = ty0 + r0, gx = tx0 + col;
+    for (int p = p0; p < p1; ++p) {
+        __syncthreads();  // the previous plane's readers are done
+#pragma unroll
+        for (int i = 0; i < fw::FNLD; ++i)
+            if (sofs[i] >= 0) tile[sofs[i]] = pre[i];
+        __syncthreads();
+        if (p + 1 < p1) fetch(p + 1);
+        const float4 *tl = tile + r0 * fw::FHW + col;
+        // MODE 0: every kd; 1: the halo plane below the slice (only tap kd = 0, output d0); 2: the one above (only kd = 2)
+        auto taps = [&](auto mode) {
+            constexpr int MODE = decltype(mode)::value;
+#pragma unroll 1
+            for (int q = 0; q < 4; ++q) {
+#pragma unroll 1
+                for (int kw = 0; kw < 3; ++kw) {
+                    const float *wq = WL == 0 ? wt + kw * 16 + q * 4 : wt + q * 108 + kw;  // wave-uniform: scalar loads
+                    float4 v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = tl[q * fw::PITCH + r * fw::FHW + kw];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const int kh = r - j;
+                            if (kh < 0 || kh > 2) continue;
+#pragma unroll
+                            for (int kd = 0; kd < 3; ++kd) {
+                                if ((MODE == 1 && kd != 0) || (MODE == 2 && kd != 2)) continue;
+                                const int tap9 = kd * 9 + kh * 3;
+                                const float w0 = WL == 0 ? wq[tap9 * 16 + 0] : wq[0 * 27 + tap9];
+                                const float w1 = WL == 0 ? wq[tap9 * 16 + 1] : wq[1 * 27 + tap9];
+                                const float w2 = WL == 0 ? wq[tap9 * 16 + 2] : wq[2 * 27 + tap9];
+                                const float w3 = WL == 0 ? wq[tap9 * 16 + 3] : wq[3 * 27 + tap9];
+                                acc[j][kd][0] = fmaf(v[r].x, w0, acc[j][kd][0]);
+                                acc[j][kd][1] = fmaf(v[r].y, w1, acc[j][kd][1]);
+                                acc[j][kd][0] = fmaf(v[r].z, w2, acc[j][kd][0]);
+                                acc[j][kd][1] = fmaf(v[r].w, w3, acc[j][kd][1]);
+                            }
+                        }
+                }
+            }
+        };
+        if (p < d0) taps(std::integral_constant<int, 1>());
+        else if (p >= d1) taps(std::integral_constant<int, 2>());
+        else taps(std::integral_constant<int, 0>());
+        // plane p is tap kd of output d = p + 1 - kd: output p-1 is complete; the volume's last plane completes output p too
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int d = e ? p : p - 1;
+            if (e && p + 1 < dm.D) break;
+            if (d < d0 || d >= d1) continue;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float s = e ? acc[j][1][0] + acc[j][1][1] : acc[j][2][0] + acc[j][2][1];
+                if (gy0 + j < dm.H && gx < dm.W) y[((size_t)b * dm.D + d) * plane + (size_t)(gy0 + j) * dm.W + gx] = s;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                acc[j][2][c] = acc[j][1][c];
+                acc[j][1][c] = acc[j][0][c];
+                acc[j][0][c] = 0.f;
+            }
+    }
+}
+
 int c1_dims(const char *fn, int B, int C, int D, int H, int W, C1Dims &dm) {
     MD_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0, "%s: bad dims B=%d D=%d H=%d W=%d", fn, B, D, H, W);
     MD_REQUIRE(C == 8 || C == 16, "%s: C=%d unsupported (8 or 16 input channels)", fn, C);
@@ -347,6 +702,21 @@ int c1_dims(const char *fn, int B, int C, int D, int H, int W, C1Dims &dm) {
     return MD_OK;
 }
 
+// geometry of the second-generation forward (16x32 tiles); a slice re-reads 2 halo planes, so at least 12 planes each
+void c1_fwd16_dims(C1Dims &dm) {
+    dm.tiles_x = md_cdiv(dm.W, fw::FTW);
+    dm.tiles = dm.tiles_x * md_cdiv(dm.H, fw::FTH);
+    int ds = 1;
+    while (ds * 2 <= dm.D / 12 && (long long)dm.B * dm.tiles * ds < 512) ds *= 2;
+    dm.planes = md_cdiv(dm.D, ds);
+    dm.dslices = md_cdiv(dm.D, dm.planes);
+}
+
+bool c1_gen1() {  // MD_CONV3D_C1_GEN1=1: the first-generation kernels for every shape (A/B measurements)
+    static const bool v = [] { const char *e = getenv("MD_CONV3D_C1_GEN1"); return e && *e == '1'; }();
+    return v;
+}
+
 }  // namespace
 
 extern "C" {
@@ -357,8 +727,17 @@ int md_conv3d_c1_fwd(const float *x, const float *wt, long long w_stride_k, long
     MD_REQUIRE(((uintptr_t)x % 16) == 0, "md_conv3d_c1_fwd: x must be 16-byte aligned");
     C1Dims dm;
     if (int rc = c1_dims("md_conv3d_c1_fwd", B, C, D, H, W, dm)) return rc;
-    const dim3 grid(B * dm.tiles * dm.dslices), block(256);
     hipStream_t s = (hipStream_t)stream;
+    const int wl = (w_stride_k == 16 && w_stride_c == 1) ? 0 : (w_stride_k == 1 && w_stride_c == 27) ? 1 : -1;
+    if (C == 16 && wl >= 0 && !c1_gen1()) {
+        c1_fwd16_dims(dm);
+        const dim3 grid16(B * dm.tiles * dm.dslices);
+        if (wl == 0) hipLaunchKernelGGL(conv3d_c1_fwd16_kernel<0>, grid16, dim3(256), 0, s, x, wt, y, dm);
+        else hipLaunchKernelGGL(conv3d_c1_fwd16_kernel<1>, grid16, dim3(256), 0, s, x, wt, y, dm);
+        MD_CHECK_LAUNCH("md_conv3d_c1_fwd");
+        return MD_OK;
+    }
+    const dim3 grid(B * dm.tiles * dm.dslices), block(256);
     if (C == 8) hipLaunchKernelGGL(conv3d_c1_fwd_kernel<2>, grid, block, 0, s, x, wt, w_stride_k, w_stride_c, y, dm);
     else hipLaunchKernelGGL(conv3d_c1_fwd_kernel<4>, grid, block, 0, s, x, wt, w_stride_k, w_stride_c, y, dm);
     MD_CHECK_LAUNCH("md_conv3d_c1_fwd");
@@ -374,7 +753,17 @@ int md_conv3d_c1_bwd_data(const float *gy, const float *wt, long long w_stride_k
     const dim3 grid(B * dm.tiles * dm.dslices), block(256);
     hipStream_t s = (hipStream_t)stream;
     if (C == 8) hipLaunchKernelGGL(conv3d_c1_bwd_data_kernel<2>, grid, block, 0, s, gy, wt, w_stride_k, w_stride_c, dx, dm);
-    else hipLaunchKernelGGL(conv3d_c1_bwd_data_kernel<4>, grid, block, 0, s, gy, wt, w_stride_k, w_stride_c, dx, dm);
+    else if (c1_gen1()) hipLaunchKernelGGL(conv3d_c1_bwd_data_kernel<4>, grid, block, 0, s, gy, wt, w_stride_k, w_stride_c, dx, dm);
+    else {
+        // own slicing: the staged gy of a slice must fit LDS
+        int ds = dm.dslices;
+        while (md_cdiv(D, ds) > BD_MAX_PLANES) ++ds;
+        dm.planes = md_cdiv(D, ds);
+        dm.dslices = md_cdiv(D, dm.planes);
+        const size_t lds_bytes = (size_t)(dm.planes + 2) * BD_PS * sizeof(float);
+        hipLaunchKernelGGL(conv3d_c1_bwd_data_mfma_kernel, dim3(B * dm.tiles * dm.dslices), block, lds_bytes, s, gy, wt, w_stride_k,
+                           w_stride_c, dx, dm);
+    }
     MD_CHECK_LAUNCH("md_conv3d_c1_bwd_data");
     return MD_OK;
 }
@@ -397,7 +786,9 @@ int md_conv3d_c1_bwd_weight(const float *x, const float *gy, float *dwt, long lo
     hipStream_t s = (hipStream_t)stream;
     float *partial = (float *)ws;
     if (C == 8) hipLaunchKernelGGL(conv3d_c1_bwd_weight_kernel<2>, grid, block, 0, s, x, gy, partial, dm);
-    else hipLaunchKernelGGL(conv3d_c1_bwd_weight_kernel<4>, grid, block, 0, s, x, gy, partial, dm);
+    else if (c1_gen1()) hipLaunchKernelGGL(conv3d_c1_bwd_weight_kernel<4>, grid, block, 0, s, x, gy, partial, dm);
+    else if (H % TH || W % TW) hipLaunchKernelGGL(conv3d_c1_bwd_weight_mfma_kernel<true>, grid, block, 0, s, x, gy, partial, dm);
+    else hipLaunchKernelGGL(conv3d_c1_bwd_weight_mfma_kernel<false>, grid, block, 0, s, x, gy, partial, dm);
     MD_CHECK_LAUNCH("md_conv3d_c1_bwd_weight");
     hipLaunchKernelGGL(conv3d_c1_bwd_weight_finish_kernel, dim3(27 * C), block, 0, s, partial, nwg, 27 * C, C, dw_stride_k,
                        dw_stride_c, dwt);

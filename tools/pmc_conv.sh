@@ -1,6 +1,6 @@
 #!/bin/bash
 # PMC counters for the regulariser's hand-written convolutions (separate passes; --kernel-trace only).
-# usage: tools/pmc_conv.sh <out.txt>
+# usage: [SCRIPTS=bench_conv3d_c1] tools/pmc_conv.sh <out.txt>
 set -u
 OUT=$1
 cd /tmp && export TMPDIR=/tmp
@@ -13,7 +13,7 @@ PASSES=(
 )
 i=0
 for P in "${PASSES[@]}"; do
-  for S in bench_conv3d_c16 bench_conv3d_c1; do
+  for S in ${SCRIPTS:-bench_conv3d_c16 bench_conv3d_c1}; do
     NO_LIB=1 rocprofv3 --kernel-trace --pmc $P --output-format csv -d /tmp/pmcc_${i}_$S -o p -- python $ROOT/tools/$S.py > /tmp/pmcc_${i}_$S.log 2>&1
   done
   i=$((i+1))
