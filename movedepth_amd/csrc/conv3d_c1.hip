@@ -48,6 +48,7 @@ constexpr int TH = 8, TW = 32, HW_ = TW + 2, HH_ = TH + 2, CELLS = HH_ * HW_;  /
 struct C1Dims {
     int B, C, D, H, W;
     int tiles_x, tiles, dslices, planes;  // planes per D slice
+    int per_xcd;                          // forward: items per XCD (0 = blockIdx is the item)
 };
 
 __device__ __forceinline__ void c1_item(const C1Dims &dm, int item, int &b, int &ty0, int &tx0, int &d0, int &d1) {
@@ -581,12 +582,19 @@ static_assert(PITCH % 16 == 4, "quad planes must sit 4 slots apart");
 template <int WL>
 __global__ __launch_bounds__(256) void conv3d_c1_fwd16_kernel(const float *__restrict__ x, const float *__restrict__ wt,
                                                               float *__restrict__ y, const C1Dims dm) {
-    __shared__ float4 tile[4 * fw::PITCH];
+    __shared__ float4 tile[fw::FNLD * 256];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int col = lane & 31, r0 = wave * 4 + (lane >> 5) * 2;  // output voxels (r0, col) and (r0 + 1, col) of the tile
     int b, ty0, tx0, d0, d1;
     {
-        const int item = blockIdx.x, sl = item % dm.dslices, t = (item / dm.dslices) % dm.tiles;
+        // Workgroup w runs on XCD w % 8, each with its own L2.  Neighbouring slices of a tile share two halo planes and
+        // neighbouring tiles a two-cell rim, so each XCD gets a contiguous run of items instead of every eighth one.
+        int item = blockIdx.x;
+        if (dm.per_xcd) {
+            item = (blockIdx.x & 7) * dm.per_xcd + (blockIdx.x >> 3);
+            if ((int)(blockIdx.x >> 3) >= dm.per_xcd || item >= dm.B * dm.tiles * dm.dslices) return;
+        }
+        const int sl = item % dm.dslices, t = (item / dm.dslices) % dm.tiles;
         b = item / (dm.dslices * dm.tiles);
         tx0 = (t % dm.tiles_x) * fw::FTW;
         ty0 = (t / dm.tiles_x) * fw::FTH;
@@ -596,20 +604,22 @@ __global__ __launch_bounds__(256) void conv3d_c1_fwd16_kernel(const float *__res
     if (d0 >= d1) return;
     const size_t plane = (size_t)dm.H * dm.W;
     const float4 *xb = reinterpret_cast<const float4 *>(x) + (size_t)b * dm.D * plane * 4;
+    // Staging is unconditional (clamped address, zeroed when written to LDS, pieces beyond the tile into spare LDS).
+    // Measured and dropped: storing an output plane one step late, ahead of the next step's loads (84 -> 100 us: the loads
+    // queue behind the stores); LDS reads one round ahead (151 registers, 3 waves per SIMD: 100 us).
     int lofs[fw::FNLD], sofs[fw::FNLD];  // global float4 offset inside a plane (-1: zero), LDS slot
 #pragma unroll
     for (int i = 0; i < fw::FNLD; ++i) {
         const int idx = tid + i * 256, cell = idx >> 2, qq = idx & 3;
         const int yy = ty0 - 1 + cell / fw::FHW, xx = tx0 - 1 + cell % fw::FHW;
         lofs[i] = (idx < fw::FCELLS * 4 && yy >= 0 && yy < dm.H && xx >= 0 && xx < dm.W) ? (yy * dm.W + xx) * 4 + qq : -1;
-        sofs[i] = idx < fw::FCELLS * 4 ? qq * fw::PITCH + cell : -1;
+        sofs[i] = idx < fw::FCELLS * 4 ? qq * fw::PITCH + cell : idx;
     }
     const int p0 = max(d0 - 1, 0), p1 = min(d1 + 1, dm.D);
     float4 pre[fw::FNLD];
     auto fetch = [&](int p) {
 #pragma unroll
-        for (int i = 0; i < fw::FNLD; ++i)
-            pre[i] = lofs[i] >= 0 ? xb[(size_t)p * plane * 4 + lofs[i]] : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = 0; i < fw::FNLD; ++i) pre[i] = xb[(size_t)p * plane * 4 + max(lofs[i], 0)];
     };
     fetch(p0);
     float acc[2][3][2];  // [voxel][kd][even / odd channel chain]
@@ -621,8 +631,7 @@ __global__ __launch_bounds__(256) void conv3d_c1_fwd16_kernel(const float *__res
     for (int p = p0; p < p1; ++p) {
         __syncthreads();  // the previous plane's readers are done
 #pragma unroll
-        for (int i = 0; i < fw::FNLD; ++i)
-            if (sofs[i] >= 0) tile[sofs[i]] = pre[i];
+        for (int i = 0; i < fw::FNLD; ++i) tile[sofs[i]] = lofs[i] >= 0 ? pre[i] : make_float4(0.f, 0.f, 0.f, 0.f);
         __syncthreads();
         if (p + 1 < p1) fetch(p + 1);
         const float4 *tl = tile + r0 * fw::FHW + col;
@@ -690,7 +699,7 @@ int c1_dims(const char *fn, int B, int C, int D, int H, int W, C1Dims &dm) {
     MD_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0, "%s: bad dims B=%d D=%d H=%d W=%d", fn, B, D, H, W);
     MD_REQUIRE(C == 8 || C == 16, "%s: C=%d unsupported (8 or 16 input channels)", fn, C);
     MD_REQUIRE((long long)D * H * W * C < (1ll << 31), "%s: one sample must stay below 2^31 elements", fn);
-    dm.B = B; dm.C = C; dm.D = D; dm.H = H; dm.W = W;
+    dm.B = B; dm.C = C; dm.D = D; dm.H = H; dm.W = W; dm.per_xcd = 0;
     dm.tiles_x = md_cdiv(W, TW);
     dm.tiles = dm.tiles_x * md_cdiv(H, TH);
     // D slices: enough workgroups to fill the chip a few times over, at least 8 planes each (a slice re-reads 2
@@ -710,6 +719,10 @@ void c1_fwd16_dims(C1Dims &dm) {
     while (ds * 2 <= dm.D / 12 && (long long)dm.B * dm.tiles * ds < 512) ds *= 2;
     dm.planes = md_cdiv(dm.D, ds);
     dm.dslices = md_cdiv(dm.D, dm.planes);
+    // off by default: measured 82.0 / 82.4 us with it against 82.8 / 80.1 us without (the halo re-reads are L2 / MALL hits
+    // either way); MD_CONV3D_C1_XCD=1 switches it on
+    static const bool xcd = [] { const char *e = getenv("MD_CONV3D_C1_XCD"); return e && *e == '1'; }();
+    dm.per_xcd = xcd ? md_cdiv(dm.B * dm.tiles * dm.dslices, 8) : 0;
 }
 
 bool c1_gen1() {  // MD_CONV3D_C1_GEN1=1: the first-generation kernels for every shape (A/B measurements)
@@ -731,7 +744,7 @@ int md_conv3d_c1_fwd(const float *x, const float *wt, long long w_stride_k, long
     const int wl = (w_stride_k == 16 && w_stride_c == 1) ? 0 : (w_stride_k == 1 && w_stride_c == 27) ? 1 : -1;
     if (C == 16 && wl >= 0 && !c1_gen1()) {
         c1_fwd16_dims(dm);
-        const dim3 grid16(B * dm.tiles * dm.dslices);
+        const dim3 grid16(dm.per_xcd ? 8 * dm.per_xcd : B * dm.tiles * dm.dslices);
         if (wl == 0) hipLaunchKernelGGL(conv3d_c1_fwd16_kernel<0>, grid16, dim3(256), 0, s, x, wt, y, dm);
         else hipLaunchKernelGGL(conv3d_c1_fwd16_kernel<1>, grid16, dim3(256), 0, s, x, wt, y, dm);
         MD_CHECK_LAUNCH("md_conv3d_c1_fwd");

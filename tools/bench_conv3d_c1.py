@@ -29,15 +29,43 @@ def ev(fn, n=20, warm=3):
 # one graph per direction: needs_input_grad follows requires_grad of the forward's inputs, so a graph in which both x
 # and w require grad runs BOTH backward kernels whatever `inputs=` autograd.grad is given (the first version of this
 # script did that and reported the sum of the two as each one's time)
-xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
-yh_dx = ops.conv3d_c1(xr, w)
-yh_dw = ops.conv3d_c1(x, wr)
+# ROTATE input volumes (default 4 = 1.1 GB) so that no launch finds its input in the 256 MB Infinity Cache: re-reading one
+# 283 MB volume measured the weight gradient at 63 us where the training step sees 94 us (profiles/r02_*)
+ROT = int(os.environ.get("ROTATE", 4))
+xs = [x] + [torch.randn_like(x) for _ in range(ROT - 1)]
+gys = [gy] + [torch.randn_like(gy) for _ in range(ROT - 1)]
+xrs = [t.clone().requires_grad_(True) for t in xs]
+wr = w.clone().requires_grad_(True)
+yh_dx = [ops.conv3d_c1(t, w) for t in xrs]
+yh_dw = [ops.conv3d_c1(t, wr) for t in xs]
 mask = lambda m: torch.ops.aten.convolution_backward(gy, x, w, None, [1] * 3, [1] * 3, [1] * 3, False, [0] * 3, 1, m)
-rows = [("fwd", lambda: ops.conv3d_c1(x, w), lambda: torch.nn.functional.conv3d(x, w, padding=1), xb + yb),
-        ("bwd-data", lambda: torch.autograd.grad(yh_dx, xr, gy, retain_graph=True), lambda: mask([True, False, False]), xb + yb),
-        ("bwd-weight", lambda: torch.autograd.grad(yh_dw, wr, gy, retain_graph=True), lambda: mask([False, True, False]), xb + yb)]
+it = [0]
+
+
+def nxt():
+    it[0] += 1
+    return it[0] % ROT
+
+
+def f_fwd():
+    ops.conv3d_c1(xs[nxt()], w)
+
+
+def f_bd():
+    i = nxt()
+    torch.autograd.grad(yh_dx[i], xrs[i], gys[i], retain_graph=True)
+
+
+def f_bw():
+    i = nxt()
+    torch.autograd.grad(yh_dw[i], wr, gys[i], retain_graph=True)
+
+
+rows = [("fwd", f_fwd, lambda: torch.nn.functional.conv3d(x, w, padding=1), xb + yb),
+        ("bwd-data", f_bd, lambda: mask([True, False, False]), xb + yb),
+        ("bwd-weight", f_bw, lambda: mask([False, True, False]), xb + yb)]
 skip_lib = os.environ.get("NO_LIB") == "1"
-print("conv3d_c1 B=%d C=%d %dx%dx%d  lib=%s" % (B, C, D, H, W, os.environ.get("MOVEDEPTH_HIP_LIB", "default")))
+print("conv3d_c1 B=%d C=%d %dx%dx%d  lib=%s  rotating over %d input volumes" % (B, C, D, H, W, os.environ.get("MOVEDEPTH_HIP_LIB", "default"), ROT))
 for name, mine, lib, nbytes in rows:
     t = ev(mine)
     tl = float("nan") if skip_lib else ev(lib, n=5, warm=2)
