@@ -95,6 +95,9 @@ struct CvDims {
     int tiles_x, tiles, splits;  // pixel tiles per sample (x, total) and channel splits
     int items;                   // B * tiles * splits work items of D hypotheses each
     int dbg;                     // unused
+    // channels-last kernels, two-phase schedule (0 = plain linear shares): workgroups [0, nc) take one of the items' k1 equal
+    // slices each, workgroups >= nc take 1/fsub of one of the remaining slices (see launch_cl_inst)
+    int k1, nc, fsub;
     unsigned long long *stats;   // md_costvol_stats: per-launch counters (null: off)
     long long sb, sd, sg, sp;
 };
@@ -133,6 +136,29 @@ struct Slots {
 struct Seg {
     int b, tile, gs, d0, d1;
 };
+// This workgroup's share [lo, hi) of the items x D hypothesis steps.
+__device__ __forceinline__ void cv_share(const CvDims &dm, long long &lo, long long &hi) {
+    const long long total = (long long)dm.items * dm.D;
+    if (dm.k1 <= 0) {
+        lo = total * blockIdx.x / gridDim.x;
+        hi = total * (blockIdx.x + 1) / gridDim.x;
+        return;
+    }
+    const int bid = blockIdx.x;
+    const int sl = bid < dm.nc ? bid : dm.nc + (bid - dm.nc) / dm.fsub;  // coarse slice
+    const int item = sl / dm.k1, part = sl - item * dm.k1;
+    const long long l0 = (long long)item * dm.D + (long long)part * dm.D / dm.k1;
+    const long long l1 = (long long)item * dm.D + (long long)(part + 1) * dm.D / dm.k1;
+    if (bid < dm.nc) {
+        lo = l0;
+        hi = l1;
+    } else {
+        const int sub = (bid - dm.nc) % dm.fsub;
+        lo = l0 + (l1 - l0) * sub / dm.fsub;
+        hi = l0 + (l1 - l0) * (sub + 1) / dm.fsub;
+    }
+}
+
 __device__ __forceinline__ bool next_segment(const CvDims &dm, long long &lo, long long hi, Seg &sg) {
     if (lo >= hi) return false;
     const int item = (int)(lo / dm.D);
@@ -698,6 +724,8 @@ struct CvPtrs {
 // (occupancy query), each workgroup taking an equal contiguous share of the items x D hypothesis steps.
 template <bool BWD, int N, int LPP, int NW, bool FUSED>
 int launch_cl_inst(const CvPtrs &q, const CvDims &dm, hipStream_t stream) {
+    CvDims dm2 = dm;
+    dm2.k1 = dm2.nc = dm2.fsub = 0;
     const void *fn = BWD ? (const void *)cl_bwd_kernel<N, LPP, NW, FUSED> : (const void *)cl_fwd_kernel<N, LPP, NW, FUSED>;
     const long long total = (long long)dm.items * dm.D;
     long long nwg = env_int(BWD ? "MD_COSTVOL_NWG_BWD" : "MD_COSTVOL_NWG", 0);
@@ -719,19 +747,39 @@ int launch_cl_inst(const CvPtrs &q, const CvDims &dm, hipStream_t stream) {
         if (k > dm.D / 8) k = dm.D / 8;
         if (k < 1) k = 1;
         nwg = (long long)dm.items * k;
+        // Two-phase schedule.  With more slices than slots the last round is partly empty (config 2: 720 slices on 512
+        // slots = one full round and one 40 % full, both as long as a slice: the wave-residency counters show every wave
+        // resident for half of the kernel's duration).  The slices of that last round are cut into `fsub` pieces so that
+        // they fill the slots once more: makespan (rounds - 1) * L + L / fsub instead of rounds * L.  Long shares first.
+        dm2.k1 = (int)k;
+        dm2.nc = (int)nwg;
+        dm2.fsub = 1;
+        // Backward only: measured at config 2, backward 97-103 -> 90-91 us stand-alone and 95.6 -> 90.8 us in the training
+        // step; the forward (store-bound, 24-step pieces re-stage their window) got slower, 60 -> 63 us, and keeps plain slices.
+        if (nwg > slots && env_int("MD_COSTVOL_TWO_PHASE", BWD ? 1 : 0)) {
+            const long long full = nwg / slots * slots, rest = nwg - full;
+            long long f = rest > 0 ? slots / rest : 1;
+            while (f > 1 && dm.D / k / f < 8) --f;
+            if (rest > 0 && f > 1) {
+                dm2.nc = (int)full;
+                dm2.fsub = (int)f;
+                nwg = full + rest * f;
+            }
+        }
     }
-    if (nwg > total) nwg = total;
-    if (nwg * ITV_MAX < total) nwg = (total + ITV_MAX - 1) / ITV_MAX;  // a share fits the interval table
+    if (dm2.k1 > 0 && dm.D / dm2.k1 > ITV_MAX) dm2.k1 = 0;  // an item-aligned slice must fit the interval table: plain shares
+    if (nwg > total) { nwg = total; dm2.k1 = 0; }
+    if (nwg * ITV_MAX < total) { nwg = (total + ITV_MAX - 1) / ITV_MAX; dm2.k1 = 0; }  // a share fits the interval table
     const dim3 grid((unsigned)nwg), block(64 * NW);
     const char *tname = BWD ? MD_CV_STR(MD_CV_NAME(md_costvol_bwd)) : MD_CV_STR(MD_CV_NAME(md_costvol_fwd));
     hipEvent_t ev0, ev1;
     md_timing_pair(tname, &ev0, &ev1);
     if (BWD)
         hipExtLaunchKernelGGL((cl_bwd_kernel<N, LPP, NW, FUSED>), grid, block, 0, stream, ev0, ev1, 0, q.gout, q.ref, q.src,
-                              q.K, q.invK, q.pose, q.hyp, q.prior, q.ztrans, q.d_ref, q.d_src, dm);
+                              q.K, q.invK, q.pose, q.hyp, q.prior, q.ztrans, q.d_ref, q.d_src, dm2);
     else
         hipExtLaunchKernelGGL((cl_fwd_kernel<N, LPP, NW, FUSED>), grid, block, 0, stream, ev0, ev1, 0, q.ref, q.src, q.K,
-                              q.invK, q.pose, q.hyp, q.prior, q.ztrans, q.out, dm);
+                              q.invK, q.pose, q.hyp, q.prior, q.ztrans, q.out, dm2);
     MD_CHECK_LAUNCH(BWD ? "md_costvol_bwd (channels-last)" : "md_costvol_fwd (channels-last)");
     return MD_OK;
 }

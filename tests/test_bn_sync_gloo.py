@@ -34,7 +34,11 @@ def test_fused_bn_sync_two_ranks_equals_big_batch():
     gys = [rng.standard_normal((2, 16, 4, 6, 8)).astype(np.float32) for _ in range(2)]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    ps = [ctx.Process(target=_worker, args=(r, 2, 29641, xs, gys, q)) for r in range(2)]
+    import socket
+    with socket.socket() as sk:  # a free port: the suite may share the box with other runs
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, xs, gys, q)) for r in range(2)]
     for p in ps:
         p.start()
     got = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])

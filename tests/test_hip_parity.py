@@ -79,6 +79,13 @@ def test_costvol_golden(ops, tag, layout):
     # single-frame fast path (fusion skipped): identical to 1e-6
     cor_fast, _ = ops.fuse_volumes([vol.detach()], layout=layout)
     assert relerr(host(cor_fast), g["cor_feats"]) < 1e-4
+    # ... and its backward (the identity: the term through the confidence weight it drops is O(1e-8) of the gradient)
+    ref2, src2 = dev(g["ref"], True), dev(g["src0"], True)
+    vol2 = ops.costvol_grouped(ref2, src2, dev(g["K"]), dev(g["invK"]), dev(g["pose"][:, 0]), G, depth_priors=dev(g["hyp"]),
+                               layout=layout)
+    (ops.fuse_volumes([vol2], layout=layout)[0] * dev(g["grad_out"])).sum().backward()
+    assert_close(host(ref2.grad), g["d_ref"], what="d_ref through the single-frame fast path")
+    assert_close(host(src2.grad), g["d_src0"], what="d_src through the single-frame fast path")
 
 
 def test_costvol_ungrouped_golden(ops):
