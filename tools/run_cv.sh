@@ -1,3 +1,7 @@
-run() { echo "=== $*"; env "$@" python tools/bench_costvol.py --layout ndhwc --iters 10 2>&1 | grep -E "kernel only.*bwd" | cut -c60-200; }
+run() { echo "=== $*"; env "$@" python tools/bench_costvol.py --layout ndhwc --iters 10 2>&1 | grep -E "kernel only.*fwd" | cut -c60-200; }
 run PRIOR=smooth
-for v in 4 5; do run PRIOR=smooth MOVEDEPTH_HIP_LIB=$GRAFT_REPO_ROOT/gpurun_probe_lib$v.so; done
+run PRIOR=smooth MD_COSTVOL_NWG=1080
+run PRIOR=smooth MD_COSTVOL_NWG=1440
+run PRIOR=smooth MD_COSTVOL_NWG=512
+run PRIOR=smooth MD_COSTVOL_NWG=360
+run PRIOR=smooth
