@@ -92,6 +92,37 @@ def cpu_baseline(opt):
                       "thread (what the reference's trainer.py:2-4 forces)" % (D, G, H, W, n, dt, all_threads, n1, dt1)}
 
 
+def _find_db_hits(device_index, limit_s=0.2):
+    """Find calls for two 2-D convolutions of the bench workload (ResNet-18 layer1 / layer2 at 192x640, batch 6: both in the
+    shipped db).  Measured on MI355X: 0.05 s each on a hit, 0.54 s on a miss (an empty user db)."""
+    import time
+
+    dev = torch.device("cuda", device_index)
+    prev = torch.backends.cudnn.benchmark
+    worst = 0.0
+    try:
+        torch.backends.cudnn.benchmark = False
+        torch.nn.functional.conv2d(torch.randn(1, 64, 8, 8, device=dev), torch.randn(64, 64, 3, 3, device=dev), padding=1)
+        torch.cuda.synchronize(dev)  # library start-up, not timed
+        torch.backends.cudnn.benchmark = True
+        for c, h, w_ in ((64, 48, 160), (128, 24, 80)):
+            x = torch.randn(6, c, h, w_, device=dev).contiguous(memory_format=torch.channels_last)
+            wt = torch.randn(c, c, 3, 3, device=dev).contiguous(memory_format=torch.channels_last)
+            torch.cuda.synchronize(dev)
+            t0 = time.time()
+            torch.nn.functional.conv2d(x, wt, padding=1)
+            torch.cuda.synchronize(dev)
+            worst = max(worst, time.time() - t0)
+    except Exception as e:  # noqa: BLE001 -- any failure means "do not rely on the db"
+        sys.stderr.write("bench: find-db probe failed (%s): searching the 3-D convolutions only\n" % e)
+        return False
+    finally:
+        torch.backends.cudnn.benchmark = prev
+    sys.stderr.write("bench: find-db probe %.2f s -> %s\n" % (worst, "shipped solver choices for all convolutions" if worst < limit_s
+                                                             else "miss: solver search for the 3-D convolutions only"))
+    return worst < limit_s
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -135,6 +166,12 @@ def main():
             "--res_arch", "18", "--prior_scale", "2", "--convex_up", "--weights_init", "scratch", "--learning_rate", "2e-4",
             "--local_rank", str(local_rank)]
     argv += a.trainer_args.split()
+    if "--miopen_find" not in argv:
+        # The in-tree MIOpen find-db holds the solver-search results of EVERY convolution of this workload (tools/
+        # make_miopen_cache.sh; the search itself takes ~9 minutes per process).  Use them if this MIOpen honours the file
+        # (same build / device: a hit answers a find call in tens of milliseconds, a miss runs the search for that problem);
+        # otherwise only the 3-D regulariser's convolutions are searched, as before.
+        argv += ["--miopen_find", "2" if _find_db_hits(local_rank if not os.environ.get("MD_SHARE_GPU") == "1" else 0) else "1"]
     if world > 1:
         argv.append("--ddp")
     share_gpu = os.environ.get("MD_SHARE_GPU", "0") == "1"

@@ -81,7 +81,7 @@ class MonodepthOptions:
         p.add_argument("--automask_noise", type=str, default="device", choices=["device", "host"],
                        help="where the 1e-5 auto-mask tie-break noise is drawn: 'host' reproduces the reference's "
                             "torch.randn(CPU).to(device) draws, 'device' avoids the per-step host round trip")
-        p.add_argument("--miopen_find", type=int, default=1, help="MIOpen solver search for the 3-D regulariser's convolutions")
+        p.add_argument("--miopen_find", type=int, default=1, help="MIOpen solver search: 0 off, 1 the 3-D regulariser's convolutions, 2 every convolution")
         p.add_argument("--reg3d_channels_last", type=int, default=1,
                        help="run the 3-D regulariser in channels_last_3d and write the cost volume as (B,D,h,w,G)")
         p.add_argument("--hip_prob_conv", type=int, default=1,

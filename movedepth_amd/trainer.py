@@ -87,6 +87,8 @@ class Trainer:
         # library convolutions: the 3-D regulariser runs channels-last (its input volume is written in that layout by
         # the HIP kernel) with MIOpen's solver search enabled for its convs only (see networks.reg3d)
         self.models["reg3d"].find_convs = bool(opt.miopen_find)
+        if opt.miopen_find >= 2:  # every convolution of the model (minutes of solver search at the first step of a process)
+            torch.backends.cudnn.benchmark = True
         self.models["reg3d"].hip_prob = bool(opt.hip_prob_conv)
         self.models["reg3d"].hip_conv0_wgrad = opt.hip_conv0 != "none"
         self.models["reg3d"].lib_conv0_fwd_dgrad = opt.hip_conv0 == "wgrad"
