@@ -92,9 +92,10 @@ def cpu_baseline(opt):
                       "thread (what the reference's trainer.py:2-4 forces)" % (D, G, H, W, n, dt, all_threads, n1, dt1)}
 
 
-def _find_db_hits(device_index, limit_s=0.2):
+def _find_db_hits(device_index, limit_s=0.3):
     """Find calls for two 2-D convolutions of the bench workload (ResNet-18 layer1 / layer2 at 192x640, batch 6: both in the
-    shipped db).  Measured on MI355X: 0.05 s each on a hit, 0.54 s on a miss (an empty user db)."""
+    shipped db).  Measured on MI355X: 0.05-0.11 s each on a hit (the latter with two ranks sharing a GPU), 0.49-0.54 s on a miss
+    (an empty user db)."""
     import time
 
     dev = torch.device("cuda", device_index)
