@@ -92,38 +92,6 @@ def cpu_baseline(opt):
                       "thread (what the reference's trainer.py:2-4 forces)" % (D, G, H, W, n, dt, all_threads, n1, dt1)}
 
 
-def _find_db_hits(device_index, limit_s=0.3):
-    """Find calls for two 2-D convolutions of the bench workload (ResNet-18 layer1 / layer2 at 192x640, batch 6: both in the
-    shipped db).  Measured on MI355X: 0.05-0.11 s each on a hit (the latter with two ranks sharing a GPU), 0.49-0.54 s on a miss
-    (an empty user db)."""
-    import time
-
-    dev = torch.device("cuda", device_index)
-    prev = torch.backends.cudnn.benchmark
-    worst = 0.0
-    try:
-        torch.backends.cudnn.benchmark = False
-        torch.nn.functional.conv2d(torch.randn(1, 64, 8, 8, device=dev), torch.randn(64, 64, 3, 3, device=dev), padding=1)
-        torch.cuda.synchronize(dev)  # library start-up, not timed
-        torch.backends.cudnn.benchmark = True
-        for c, h, w_ in ((64, 48, 160), (128, 24, 80)):
-            x = torch.randn(6, c, h, w_, device=dev).contiguous(memory_format=torch.channels_last)
-            wt = torch.randn(c, c, 3, 3, device=dev).contiguous(memory_format=torch.channels_last)
-            torch.cuda.synchronize(dev)
-            t0 = time.time()
-            torch.nn.functional.conv2d(x, wt, padding=1)
-            torch.cuda.synchronize(dev)
-            worst = max(worst, time.time() - t0)
-    except Exception as e:  # noqa: BLE001 -- any failure means "do not rely on the db"
-        sys.stderr.write("bench: find-db probe failed (%s): searching the 3-D convolutions only\n" % e)
-        return False
-    finally:
-        torch.backends.cudnn.benchmark = prev
-    sys.stderr.write("bench: find-db probe %.2f s -> %s\n" % (worst, "shipped solver choices for all convolutions" if worst < limit_s
-                                                             else "miss: solver search for the 3-D convolutions only"))
-    return worst < limit_s
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -142,20 +110,10 @@ def main():
         raise SystemExit("launch --gpus %d with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (a.gpus, a.gpus, world))
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    # MIOpen's find results / compiled kernels for reg3d's 3-D convs (saves ~70 s of solver search per process)
-    # (a private copy per rank: MIOpen's sqlite caches are not meant to be shared by concurrent writers)
-    mc = os.path.join(ROOT, "movedepth_amd", "miopen_cache")
-    if os.path.isdir(mc) and "MIOPEN_USER_DB_PATH" not in os.environ:
-        import shutil
-        import tempfile
+    # MIOpen's find results / compiled kernels, shipped in-tree (a private copy per rank), see movedepth_amd/miopen_setup.py
+    from movedepth_amd import miopen_setup
 
-        priv = os.path.join(tempfile.gettempdir(), "movedepth_miopen_rank%d_%d" % (rank, os.getpid()))
-        try:
-            shutil.copytree(mc, priv, dirs_exist_ok=True)
-            os.environ["MIOPEN_USER_DB_PATH"] = os.path.join(priv, "db")
-            os.environ["MIOPEN_CUSTOM_CACHE_DIR"] = os.path.join(priv, "cache")
-        except OSError:
-            pass
+    miopen_setup.use_shipped_cache(rank)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
 
     from movedepth_amd import ops
@@ -168,11 +126,10 @@ def main():
             "--local_rank", str(local_rank)]
     argv += a.trainer_args.split()
     if "--miopen_find" not in argv:
-        # The in-tree MIOpen find-db holds the solver-search results of EVERY convolution of this workload (tools/
-        # make_miopen_cache.sh; the search itself takes ~9 minutes per process).  Use them if this MIOpen honours the file
-        # (same build / device: a hit answers a find call in tens of milliseconds, a miss runs the search for that problem);
-        # otherwise only the 3-D regulariser's convolutions are searched, as before.
-        argv += ["--miopen_find", "2" if _find_db_hits(local_rank if not os.environ.get("MD_SHARE_GPU") == "1" else 0) else "1"]
+        # every convolution on its searched solver when the shipped find-db is honoured here (47.3 -> 43.5 ms per step), the
+        # 3-D regulariser's only otherwise (a full search of this workload is ~9 minutes)
+        share = os.environ.get("MD_SHARE_GPU", "0") == "1"
+        argv += ["--miopen_find", "2" if miopen_setup.find_db_hits(0 if share else local_rank) else "1"]
     if world > 1:
         argv.append("--ddp")
     share_gpu = os.environ.get("MD_SHARE_GPU", "0") == "1"

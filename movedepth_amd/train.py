@@ -25,7 +25,16 @@ def seed_all(seed):
 
 
 def main():
-    opts = MovedepthOptions().parse()
+    import sys
+
+    from . import miopen_setup
+
+    argv = sys.argv[1:]
+    rank = int(os.environ.get("RANK", "0"))
+    miopen_setup.use_shipped_cache(rank)  # MIOpen's search results shipped in-tree (miopen_setup.py)
+    if "--miopen_find" not in argv and torch.cuda.is_available() and miopen_setup.find_db_hits(int(os.environ.get("LOCAL_RANK", "0"))):
+        argv += ["--miopen_find", "2"]
+    opts = MovedepthOptions().parse(argv)
     seed_all(opts.pytorch_random_seed)
     Trainer(opts).train()
 
