@@ -7,9 +7,14 @@ from torch.profiler import profile, ProfilerActivity
 from movedepth_amd.options import MovedepthOptions
 from movedepth_amd.synthetic import make_inputs
 from movedepth_amd.trainer import Trainer
+from movedepth_amd import miopen_setup
+
+miopen_setup.use_shipped_cache(0)
 
 argv = ["--height", "192", "--width", "640", "--num_depth_bins", "96", "--batch_size", "6", "--res_arch", "18", "--prior_scale", "2",
         "--convex_up", "--weights_init", "scratch", "--learning_rate", "2e-4"] + sys.argv[1:]
+if "--miopen_find" not in argv and miopen_setup.find_db_hits(0):
+    argv += ["--miopen_find", "2"]
 opt = MovedepthOptions().parse(argv)
 torch.manual_seed(0); np.random.seed(0)
 t = Trainer(opt); t.set_train()
@@ -37,3 +42,11 @@ print("total self GPU time of one step: %.2f ms over %d (op, shape) groups" % (t
 print("%-44s %-102s %6s %10s" % ("op", "input shapes", "calls", "gpu us"))
 for (k, shp), (c, us) in rows[:int(os.environ.get("TOP", "60"))]:
     print("%-44s %-102s %6d %10.0f" % (k[:44], shp, c, us))
+
+byop = collections.defaultdict(lambda: [0, 0.0])
+for (k, shp), (c, us) in rows:
+    byop[k][0] += c
+    byop[k][1] += us
+print("\n---- by op")
+for k, (c, us) in sorted(byop.items(), key=lambda kv: -kv[1][1])[:40]:
+    print("%-60s %6d calls %10.0f us" % (k[:60], c, us))
