@@ -120,6 +120,9 @@ def main():
             buf = (ctypes.c_ulonglong * 8)()
             lib.md_costvol_stats(0, buf)
             v = list(buf)
+            if os.environ.get("MD_CV_TIMELINE"):
+                print("  timeline %s (shader cycles of thread 0, summed over workgroups): %s" % (nm, v))
+                continue
             print("  stats %s: segments %d, windows staged %d, fit attempts %d, lanes redoing misses %d, cell-change blocks %d "
                   "(%.1f lanes each), wave-steps %d" % (nm, v[0], v[1], v[2], v[3], v[4], v[5] / max(v[4], 1), v[6]))
     for k, v in lib_t.items():

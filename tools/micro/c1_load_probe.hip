@@ -112,6 +112,36 @@ __global__ __launch_bounds__(256) void store_probe(float *__restrict__ big, int 
     }
 }
 
+// The plane-sweep backward's gradient read: workgroup = 16 x 4 pixel tile (wave = one row of 16 pixels = 1 KB per plane),
+// walks ALL 96 planes; BATCH planes are requested together, AHEAD batches before they are consumed.
+template <int BATCH, int AHEAD>
+__global__ __launch_bounds__(256) void sweep_probe(const float *__restrict__ x, float *__restrict__ out, int nitems) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles_x = W / 16, tiles = tiles_x * (H / 4);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+        const int t = item % tiles, b = item / tiles;
+        const int tx0 = (t % tiles_x) * 16, ty0 = (t / tiles_x) * 4;
+        const float4 *p = reinterpret_cast<const float4 *>(x + (size_t)b * D * PLANE * C) + ((ty0 + wave) * W + tx0) * 4 + lane;
+        float4 q[AHEAD + 1][BATCH];
+#pragma unroll
+        for (int a = 0; a < AHEAD; ++a)
+#pragma unroll
+            for (int j = 0; j < BATCH; ++j) q[a][j] = p[(size_t)(a * BATCH + j) * PLANE * 4];
+        for (int d = 0; d < D; d += BATCH) {
+#pragma unroll
+            for (int j = 0; j < BATCH; ++j) q[AHEAD][j] = p[(size_t)min(d + AHEAD * BATCH + j, D - 1) * PLANE * 4];
+#pragma unroll
+            for (int j = 0; j < BATCH; ++j) { acc.x += q[0][j].x; acc.y += q[0][j].y; acc.z += q[0][j].z; acc.w += q[0][j].w; }
+#pragma unroll
+            for (int a = 0; a < AHEAD; ++a)
+#pragma unroll
+                for (int j = 0; j < BATCH; ++j) q[a][j] = q[a + 1][j];
+        }
+    }
+    out[(size_t)blockIdx.x * 256 + tid] = acc.x + acc.y + acc.z + acc.w;
+}
+
 // plain stream: grid-stride float4 reads of the whole volume
 __global__ __launch_bounds__(256) void stream(const float4 *__restrict__ x, float *__restrict__ out, size_t n4) {
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -176,6 +206,19 @@ int main() {
     RUN(5, 1, false, 24, 39, "16x32 tile + halo (fwd staging), float4");
     RUN(5, 1, false, 12, 0, "16x32 tile + halo (fwd staging), float4");
     RUN(1, 1, true, 12, 0, "8x32 tile, float4 load + float4 store (copy)");
+#define SWEEP(BATCH, AHEAD, grid)                                                                                                   \
+    {                                                                                                                               \
+        char nm[128]; snprintf(nm, 128, "plane-sweep gradient read: 16x4 tile x 96 planes, batch %d, %d ahead, %d WGs", BATCH, AHEAD, grid); \
+        rep(nm, time_us([&](int i) { hipLaunchKernelGGL((sweep_probe<BATCH, AHEAD>), dim3(grid), dim3(256), 0, 0, x[i % ROT], out, B * (W / 16) * (H / 4)); }), mb); \
+    }
+    SWEEP(4, 0, 720);
+    SWEEP(4, 1, 720);
+    SWEEP(4, 2, 720);
+    SWEEP(4, 3, 720);
+    SWEEP(4, 1, 512);
+    SWEEP(4, 3, 512);
+    SWEEP(8, 1, 720);
+    SWEEP(8, 2, 720);
     float *bigs[ROT];
     bigs[0] = big;
     for (int r = 1; r < ROT; ++r) bigs[r] = x[r];
