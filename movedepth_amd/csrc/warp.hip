@@ -180,25 +180,35 @@ __global__ __launch_bounds__(256) void disp_up_fwd_kernel(const float *__restric
     depth[((size_t)b * H + y) * W + x] = 1.f / sd;
 }
 
-// Gather form of the adjoint (deterministic, no atomics): one thread per low-res pixel scans the
-// full-res pixels whose bilinear footprint can touch it.
+// Gather form of the adjoint (deterministic, no atomics): LPP lanes per low-res pixel scan the full-res pixels whose
+// bilinear footprint can touch it (a (3r+3)^2 window for an r-fold upsampling: 729 pixels at r = 8, where one thread per
+// low-res pixel meant 11,520 threads looping 729 times: 41 us per call against 5 us for the forward) and meet by shuffles.
+template <int LPP>
 __global__ __launch_bounds__(256) void disp_up_bwd_kernel(const float *__restrict__ g_depth, const float *__restrict__ disp,
-                                                          int h, int w, int H, int W, float min_disp, float max_disp,
+                                                          int B, int h, int w, int H, int W, float min_disp, float max_disp,
                                                           float *__restrict__ d_disp) {
-    const int b = blockIdx.z;
-    const int ix = blockIdx.x * 64 + (threadIdx.x & 63), iy = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (ix >= w || iy >= h) return;
-    const float ry = (float)H / (float)h, rx = (float)W / (float)w;
-    const int oy_lo = max(0, (int)floorf(((float)iy - 1.f) * ry) - 1), oy_hi = min(H - 1, (int)ceilf(((float)iy + 2.f) * ry) + 1);
-    const int ox_lo = max(0, (int)floorf(((float)ix - 1.f) * rx) - 1), ox_hi = min(W - 1, (int)ceilf(((float)ix + 2.f) * rx) + 1);
-    const float *s = disp + (size_t)b * h * w;
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long pix = gid / LPP;
+    const int sub = (int)(gid % LPP);
+    const bool live = pix < (long long)B * h * w;
     float acc = 0.f;
-    for (int oy = oy_lo; oy <= oy_hi; ++oy) {
-        int y0, y1; float ly;
-        interp_idx(oy, h, H, y0, y1, ly);
-        const float wy = (y0 == iy ? 1.f - ly : 0.f) + (y1 == iy ? ly : 0.f);
-        if (wy == 0.f) continue;
-        for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+    int b = 0, iy = 0, ix = 0;
+    if (live) {
+        b = (int)(pix / ((long long)h * w));
+        const int rem = (int)(pix - (long long)b * h * w);
+        iy = rem / w;
+        ix = rem - iy * w;
+        const float ry = (float)H / (float)h, rx = (float)W / (float)w;
+        const int oy_lo = max(0, (int)floorf(((float)iy - 1.f) * ry) - 1), oy_hi = min(H - 1, (int)ceilf(((float)iy + 2.f) * ry) + 1);
+        const int ox_lo = max(0, (int)floorf(((float)ix - 1.f) * rx) - 1), ox_hi = min(W - 1, (int)ceilf(((float)ix + 2.f) * rx) + 1);
+        const int fw = ox_hi - ox_lo + 1, n = fw * (oy_hi - oy_lo + 1);
+        const float *s = disp + (size_t)b * h * w;
+        for (int k = sub; k < n; k += LPP) {
+            const int oy = oy_lo + k / fw, ox = ox_lo + k % fw;
+            int y0, y1; float ly;
+            interp_idx(oy, h, H, y0, y1, ly);
+            const float wy = (y0 == iy ? 1.f - ly : 0.f) + (y1 == iy ? ly : 0.f);
+            if (wy == 0.f) continue;
             int x0, x1; float lx;
             interp_idx(ox, w, W, x0, x1, lx);
             const float wx = (x0 == ix ? 1.f - lx : 0.f) + (x1 == ix ? lx : 0.f);
@@ -211,7 +221,9 @@ __global__ __launch_bounds__(256) void disp_up_bwd_kernel(const float *__restric
             acc += gv * wy * wx;
         }
     }
-    d_disp[((size_t)b * h + iy) * w + ix] = acc;
+#pragma unroll
+    for (int o = 1; o < LPP; o <<= 1) acc += __shfl_xor(acc, o, 64);  // fixed tree: deterministic
+    if (live && sub == 0) d_disp[((size_t)b * h + iy) * w + ix] = acc;
 }
 
 int check_img(const char *fn, int B, int Ci, int H, int W) {
@@ -268,8 +280,14 @@ extern "C" int md_disp_to_depth_up_bwd(const float *g_depth, const float *disp, 
                                        float min_depth, float max_depth, float *d_disp, md_stream_t stream) {
     MD_REQUIRE(g_depth && disp && d_disp, "md_disp_to_depth_up_bwd: null tensor");
     MD_REQUIRE(B > 0 && B <= 65535 && h > 0 && w > 0 && H > 0 && W > 0, "md_disp_to_depth_up_bwd: bad dims");
-    hipLaunchKernelGGL(disp_up_bwd_kernel, dim3(md_cdiv(w, 64), md_cdiv(h, 4), B), dim3(256), 0, (hipStream_t)stream,
-                       g_depth, disp, h, w, H, W, 1.f / max_depth, 1.f / min_depth, d_disp);
+    const long long npix = (long long)B * h * w;
+    const int r = md_cdiv(H, h) > md_cdiv(W, w) ? md_cdiv(H, h) : md_cdiv(W, w);  // upsampling factor
+    const float lo = 1.f / max_depth, hi = 1.f / min_depth;
+    hipStream_t st = (hipStream_t)stream;
+    if (r >= 8) hipLaunchKernelGGL(disp_up_bwd_kernel<64>, dim3((unsigned)md_cdiv(npix * 64, 256)), dim3(256), 0, st, g_depth, disp, B, h, w, H, W, lo, hi, d_disp);
+    else if (r >= 4) hipLaunchKernelGGL(disp_up_bwd_kernel<16>, dim3((unsigned)md_cdiv(npix * 16, 256)), dim3(256), 0, st, g_depth, disp, B, h, w, H, W, lo, hi, d_disp);
+    else if (r >= 2) hipLaunchKernelGGL(disp_up_bwd_kernel<4>, dim3((unsigned)md_cdiv(npix * 4, 256)), dim3(256), 0, st, g_depth, disp, B, h, w, H, W, lo, hi, d_disp);
+    else hipLaunchKernelGGL(disp_up_bwd_kernel<1>, dim3((unsigned)md_cdiv(npix, 256)), dim3(256), 0, st, g_depth, disp, B, h, w, H, W, lo, hi, d_disp);
     MD_CHECK_LAUNCH("md_disp_to_depth_up_bwd");
     return MD_OK;
 }
