@@ -115,7 +115,8 @@ __global__ __launch_bounds__(256) void store_probe(float *__restrict__ big, int 
 // The plane-sweep backward's gradient read: workgroup = 16 x 4 pixel tile (wave = one row of 16 pixels = 1 KB per plane),
 // walks ALL 96 planes; BATCH planes are requested together, AHEAD batches before they are consumed.
 template <int BATCH, int AHEAD>
-__global__ __launch_bounds__(256) void sweep_probe(const float *__restrict__ x, float *__restrict__ out, int nitems) {
+__global__ __launch_bounds__(256) void sweep_probe(const float *__restrict__ x, float *__restrict__ out, int nitems, int work) {
+    extern __shared__ float dummy2[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tiles_x = W / 16, tiles = tiles_x * (H / 4);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -133,6 +134,10 @@ __global__ __launch_bounds__(256) void sweep_probe(const float *__restrict__ x, 
             for (int j = 0; j < BATCH; ++j) q[AHEAD][j] = p[(size_t)min(d + AHEAD * BATCH + j, D - 1) * PLANE * 4];
 #pragma unroll
             for (int j = 0; j < BATCH; ++j) { acc.x += q[0][j].x; acc.y += q[0][j].y; acc.z += q[0][j].z; acc.w += q[0][j].w; }
+            for (int k = 0; k < work; ++k) {  // stand-in for the batch's arithmetic: a dependent chain of 4 FMAs per round
+                acc.x = fmaf(acc.x, 1.0001f, acc.y); acc.y = fmaf(acc.y, 0.9999f, acc.z);
+                acc.z = fmaf(acc.z, 1.0001f, acc.w); acc.w = fmaf(acc.w, 0.9999f, acc.x);
+            }
 #pragma unroll
             for (int a = 0; a < AHEAD; ++a)
 #pragma unroll
@@ -206,19 +211,26 @@ int main() {
     RUN(5, 1, false, 24, 39, "16x32 tile + halo (fwd staging), float4");
     RUN(5, 1, false, 12, 0, "16x32 tile + halo (fwd staging), float4");
     RUN(1, 1, true, 12, 0, "8x32 tile, float4 load + float4 store (copy)");
-#define SWEEP(BATCH, AHEAD, grid)                                                                                                   \
+#define SWEEP(BATCH, AHEAD, grid, lds, work)                                                                                        \
     {                                                                                                                               \
-        char nm[128]; snprintf(nm, 128, "plane-sweep gradient read: 16x4 tile x 96 planes, batch %d, %d ahead, %d WGs", BATCH, AHEAD, grid); \
-        rep(nm, time_us([&](int i) { hipLaunchKernelGGL((sweep_probe<BATCH, AHEAD>), dim3(grid), dim3(256), 0, 0, x[i % ROT], out, B * (W / 16) * (H / 4)); }), mb); \
+        char nm[160]; snprintf(nm, 160, "plane-sweep gradient read: batch %d, %d ahead, %d WGs, %d KB LDS/WG, %d FMA rounds per batch", BATCH, AHEAD, grid, lds, work); \
+        rep(nm, time_us([&](int i) { hipLaunchKernelGGL((sweep_probe<BATCH, AHEAD>), dim3(grid), dim3(256), lds * 1024, 0, x[i % ROT], out, B * (W / 16) * (H / 4), work); }), mb); \
     }
-    SWEEP(4, 0, 720);
-    SWEEP(4, 1, 720);
-    SWEEP(4, 2, 720);
-    SWEEP(4, 3, 720);
-    SWEEP(4, 1, 512);
-    SWEEP(4, 3, 512);
-    SWEEP(8, 1, 720);
-    SWEEP(8, 2, 720);
+    SWEEP(4, 0, 720, 0, 0);
+    SWEEP(4, 1, 720, 0, 0);
+    SWEEP(4, 3, 720, 0, 0);
+    SWEEP(4, 1, 512, 0, 0);
+    SWEEP(4, 3, 512, 0, 0);
+    // the kernel's residency: 2 workgroups per CU (64 KB of LDS each), 720 workgroups = 1.4 rounds
+    SWEEP(4, 0, 720, 64, 0);
+    SWEEP(4, 1, 720, 64, 0);
+    SWEEP(4, 2, 720, 64, 0);
+    SWEEP(4, 0, 720, 64, 100);
+    SWEEP(4, 1, 720, 64, 100);
+    SWEEP(4, 2, 720, 64, 100);
+    SWEEP(4, 0, 720, 64, 300);
+    SWEEP(4, 1, 720, 64, 300);
+    SWEEP(4, 2, 720, 64, 300);
     float *bigs[ROT];
     bigs[0] = big;
     for (int r = 1; r < ROT; ++r) bigs[r] = x[r];
