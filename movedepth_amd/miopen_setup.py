@@ -14,6 +14,7 @@ search compiled, produced on the GPU box by tools/make_miopen_cache.sh.
 A launcher that gets True passes `--miopen_find 2` (every convolution in search mode); otherwise the trainer's default
 `--miopen_find 1` searches the regulariser's convolutions only, as it always did.
 """
+import atexit
 import os
 import shutil
 import sys
@@ -35,6 +36,7 @@ def use_shipped_cache(rank=0):
         return False
     os.environ["MIOPEN_USER_DB_PATH"] = os.path.join(priv, "db")
     os.environ["MIOPEN_CUSTOM_CACHE_DIR"] = os.path.join(priv, "cache")
+    atexit.register(shutil.rmtree, priv, ignore_errors=True)  # 2 MB per process: do not pile up in the temp directory
     return True
 
 
