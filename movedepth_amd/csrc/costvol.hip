@@ -744,6 +744,7 @@ int launch_cl_inst(const CvPtrs &q, const CvDims &dm, hipStream_t stream) {
         // item-aligned slices stage one window each; an arbitrary grid (e.g. exactly `slots`) makes most workgroups straddle
         // two items and stage twice (B=6, 48x160, D=96: 720 workgroups 67.8 us, 512 72.8 us, 1024 82.7 us)
         long long k = (slots + dm.items - 1) / dm.items;
+        if (BWD && dm.items * 10 >= slots * 9) k = 1;  // one almost-full round beats two slices per item in two rounds
         if (k > dm.D / 8) k = dm.D / 8;
         if (k < 1) k = 1;
         nwg = (long long)dm.items * k;
