@@ -125,6 +125,8 @@ def main():
             "--res_arch", "18", "--prior_scale", "2", "--convex_up", "--weights_init", "scratch", "--learning_rate", "2e-4",
             "--local_rank", str(local_rank)]
     argv += a.trainer_args.split()
+    if "--miopen_find" not in argv and a.trainer_args:
+        argv += ["--miopen_find", "1"]  # another workload: its 2-D convolutions are not in the shipped db, a search would take minutes
     if "--miopen_find" not in argv:
         # every convolution on its searched solver when the shipped find-db is honoured here (47.3 -> 43.5 ms per step), the
         # 3-D regulariser's only otherwise (a full search of this workload is ~9 minutes)
