@@ -37,9 +37,6 @@
 
 #include "md_common.hpp"
 
-#ifndef MD_C1_PROBE_BW
-#define MD_C1_PROBE_BW 0  // timing experiments on the weight-gradient kernel (1: no gy fetch in the march, 2: no MFMAs); wrong results
-#endif
 
 namespace {
 
@@ -520,10 +517,8 @@ __global__ __launch_bounds__(256) void conv3d_c1_bwd_weight_mfma_kernel(const fl
 #pragma unroll
         for (int g = 0; g < 16; ++g) xa[g] = xload(d0, g);
         auto step = [&](int d, float (&cur)[16], float (&nxt)[16]) {
-#if MD_C1_PROBE_BW != 1
             R.stash(d + 1);
-            R.fetch(gyb, dm, d + 2);  // unconditional, like the x loads below (clamped plane, unused after the last step)
-#endif
+            R.fetch(gyb, dm, d + 2);  // unconditional (clamped plane, unused after the last step)
             if (d + 1 < d1) {  // a branch is harmless here: the kernel has no stores in flight, the next wait is vmcnt(0) anyway
 #pragma unroll
                 for (int g = 0; g < 16; ++g) nxt[g] = xload(d + 1, g);
@@ -541,13 +536,8 @@ __global__ __launch_bounds__(256) void conv3d_c1_bwd_weight_mfma_kernel(const fl
                 float a1 = pB[go];
                 a1 = vB ? a1 : 0.f;
                 const float xv = xok(g) ? cur[g] : 0.f;
-#if MD_C1_PROBE_BW == 2
-                acc0[g & 3] = fmaf(a0, xv, acc0[g & 3]);
-                acc1[g & 3] = fmaf(a1, xv, acc1[g & 3]);
-#else
                 acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, xv, acc0, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, xv, acc1, 0, 0, 0);
-#endif
             }
             __builtin_amdgcn_sched_barrier(0);  // the next step's loads stay behind this step's MFMAs
         };
