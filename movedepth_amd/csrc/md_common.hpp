@@ -127,6 +127,9 @@ __device__ __forceinline__ float md_hyp_itv(int k, int D, int type) {
                                   : (float)k / (float)(D - 1);
 }
 __device__ __forceinline__ float md_hyp_eval(const HypConst &h, float itv, int type) {
+    // two roundings, as the reference's `a + b * itv` (layers.py:268-270), at every call site: the kernels that evaluate a
+    // hypothesis twice (hot loop / window-miss loop) rely on bit-identical results
+#pragma clang fp contract(off)
     const float v = h.a + h.b * itv;
     return type == MD_SCHED_INVERSE ? md_rcp_nr(v) : v;
 }

@@ -141,24 +141,24 @@ def test_process_batch_matches_reference(tag):
     # bins differ by ~1e-3 relative): a pixel whose arg-max moves to the neighbouring bin changes its depth by a few
     # per cent; allow 0.2 % of such pixels (none observed), the rest must agree to 1e-4
     for key in ("depth_mvs", "masked_depth", "fused_depth", "mvs_reprojection_loss"):
-        r, frac = _flip_tolerant(host(outputs[key]), g["out:" + key], key, rtol=1e-4, max_flip_frac=2e-3)
+        r, frac = _flip_tolerant(host(outputs[key]), g["out:" + key], key, rtol=1e-4, max_flip_frac=0.0)
         report[key], report[key + ":flips"] = r, frac
     for n, f in (("m1", -1), ("p1", 1)):
-        r, frac = _flip_tolerant(host(outputs[("mvs_color", f)]), g["out:mvs_color_" + n], "mvs_color", 1e-4, 2e-3)
+        r, frac = _flip_tolerant(host(outputs[("mvs_color", f)]), g["out:mvs_color_" + n], "mvs_color", 1e-4, 0.0)
         report["mvs_color_" + n] = r
         flips = float((host(outputs[("mvs_mask", f)]).astype(bool) != g["out:mvs_mask_" + n]).mean())
-        assert flips <= 2e-3, ("mvs_mask", n, flips)
-    r, frac = _flip_tolerant(host(outputs[("mvs_color_fuse", 1)]), g["out:mvs_color_fuse_p1"], "mvs_color_fuse", 1e-4, 2e-3)
+        assert flips == 0, ("mvs_mask", n, flips)
+    r, frac = _flip_tolerant(host(outputs[("mvs_color_fuse", 1)]), g["out:mvs_color_fuse_p1"], "mvs_color_fuse", 1e-4, 0.0)
     assert abs(float(outputs["mvs_reproj_loss"]) - float(g["out:mvs_reproj_loss"])) <= 1e-4 * float(g["out:mvs_reproj_loss"])
     # boolean / 0-1 masks: fraction of differing pixels
     flips = float((host(outputs["reprojection_loss_mask"]) != g["out:reprojection_loss_mask"]).mean())
     report["reprojection_loss_mask:flips"] = flips
-    assert flips <= 5e-3
+    assert flips == 0, ("reprojection_loss_mask", flips)
     for key in ("photo_conf_map", "dist_mask"):
         if "out:" + key in g:
             flips = float((host(outputs[key]).astype(bool) != g["out:" + key].astype(bool)).mean())
             report[key + ":flips"] = flips
-            assert flips <= 5e-3, (key, flips)
+            assert flips == 0, (key, flips)
 
     # ---- gradients: per-parameter L2 norms of every sub-model + full tensors of selected parameters
     for name, m in t.models.items():
@@ -215,6 +215,6 @@ def test_eval_forward_matches_reference(tag, matching):
     r = relerr(host(out["cor_feats"]), g["cor_feats"])
     print("\n[eval %s] cor_feats %.1e" % (tag, r))
     assert r <= 1e-4
-    r1, f1 = _flip_tolerant(host(out["depth_lowres"]), g["depth_lowres"], "depth_lowres", 1e-4, 2e-3)
-    r2, f2 = _flip_tolerant(host(out["depth_mvs"]), g["pred_depth"], "pred_depth", 1e-4, 2e-3)
+    r1, f1 = _flip_tolerant(host(out["depth_lowres"]), g["depth_lowres"], "depth_lowres", 1e-4, 0.0)
+    r2, f2 = _flip_tolerant(host(out["depth_mvs"]), g["pred_depth"], "pred_depth", 1e-4, 0.0)
     print("[eval %s] depth_lowres %.1e (flips %.1e), pred_depth %.1e (flips %.1e)" % (tag, r1, f1, r2, f2))
