@@ -148,6 +148,55 @@ int md_masked_min_fwd(const float *reproj, const float *ident, const float *nois
 int md_masked_min_bwd(const float *gloss, const float *reproj, const float *mask, const float *loss, int B, int N,
                       int H, int W, float *d_reproj, md_stream_t stream);
 
+/* ---- the photometric chain fused: warp(s) + SSIM/L1 + min over frames + auto-mask + masked mean -------------------
+ * One forward and one backward launch for everything generate_images_pred + compute_losses do for one group of losses
+ * (trainer.py:491-532 + 675-724 mono, all scales; 498-509 + 621-673 MVS; 569-612 fused depth): per scale s and source
+ * frame f  pred = grid_sample(src[f], Project3D(BackprojectDepth(depth_s), K, T[f]), border)  (layers.py:556-621),
+ * loss_f = compute_reprojection_loss(pred, target) (trainer.py:535-550, layers.py:663-677), min over f, mask =
+ * [min <= ident_min + noise_s] (trainer.py:698-705; ones with mvs_mode, trainer.py:647) x ext_mask, and
+ * loss[s] = sum(min * mask) / (sum(mask) + 1e-7).  Same arithmetic per step as md_disp_to_depth_up / md_warp /
+ * md_reproj_loss / md_masked_min above, which remain for callers that want the pieces.
+ *
+ * All images [B,3,H,W]; maps [B,H,W] (= [B,1,H,W]); K, invK, T[f] [B,4,4].  NULL output pointers are skipped. */
+#define MD_PHOTO_MAX_FRAMES 4
+#define MD_PHOTO_MAX_SCALES 4
+typedef struct md_photo_desc {
+    int B, H, W;       /* batch, full resolution */
+    int F, S;          /* source frames (1..4), scales (1..4) */
+    int is_disp;       /* dz[s] is a disparity pyramid level [B,1,dh[s],dw[s]]: F.interpolate(bilinear, align_corners=False) to
+                          HxW + disp_to_depth inside (trainer.py:512-514); else dz[s] is a depth map [B,H,W] */
+    int identity;      /* 1: no warp, pred_f = src[f]: the identity reprojection loss, min over frames -> mn[0] (trainer.py:690-696) */
+    int mvs_mode;      /* 1: the auto-mask is replaced by ones (trainer.py:647) */
+    int no_ssim;       /* 1: L1 only (--no_ssim, or ssim_lw = 0 at trainer.py:588) */
+    float ssim_w, min_depth, max_depth;
+    int dh[MD_PHOTO_MAX_SCALES], dw[MD_PHOTO_MAX_SCALES];
+    const float *target;
+    const float *src[MD_PHOTO_MAX_FRAMES];
+    const float *T[MD_PHOTO_MAX_FRAMES];
+    const float *K, *invK;
+    const float *dz[MD_PHOTO_MAX_SCALES];
+    const float *ident_min;  /* [B,H,W] min over frames of the identity loss, or NULL (no auto-mask) */
+    const float *noise;      /* [S,B,H,W] tie-break noise already scaled by 1e-5 (trainer.py:698), or NULL */
+    const float *ext_mask;   /* [B,H,W] or NULL (photo_conf_map / dist_mask, trainer.py:650-657) */
+    /* forward outputs */
+    float *warped[MD_PHOTO_MAX_SCALES][MD_PHOTO_MAX_FRAMES];  /* ("color",f,s) / ("mvs_color",f); REQUIRED by the backward */
+    float *pix[MD_PHOTO_MAX_SCALES][MD_PHOTO_MAX_FRAMES];     /* ("sample",f,s) [B,H,W,2] */
+    unsigned char *oob[MD_PHOTO_MAX_FRAMES];                  /* ("mvs_mask",f): any coordinate outside [-1,1] (trainer.py:503), scale 0 */
+    float *depth_out[MD_PHOTO_MAX_SCALES];                    /* ("depth",0,s) */
+    float *mn[MD_PHOTO_MAX_SCALES];                           /* min over frames of the reprojection loss */
+    float *mask[MD_PHOTO_MAX_SCALES];                         /* the mask as floats */
+    unsigned char *sel[MD_PHOTO_MAX_SCALES];                  /* arg-min frame | 0x80 where mask != 0; REQUIRED by the backward */
+    float *loss;                                              /* [S][2]: loss, sum(mask) */
+    /* backward only */
+    const float *gloss[MD_PHOTO_MAX_SCALES];  /* d L / d loss[s]: device scalars, NULL = 0 */
+    float *d_dz[MD_PHOTO_MAX_SCALES];         /* gradient w.r.t. dz[s], same shape */
+    float *d_T[MD_PHOTO_MAX_FRAMES];          /* [B,4,4] summed over scales, or NULL (T detached, trainer.py:499) */
+} md_photo_desc;
+size_t md_photo_fwd_ws_bytes(int B, int S, int H, int W);
+int md_photo_fwd(const md_photo_desc *desc, void *ws, md_stream_t stream);
+size_t md_photo_bwd_ws_bytes(int B, int S, int F, int H, int W, int is_disp);
+int md_photo_bwd(const md_photo_desc *desc, void *ws, md_stream_t stream);
+
 /* ---- edge-aware smoothness ---------------------------------------------------------------
  * get_smooth_loss (layers.py:630-643) on disp / (mean_hw(disp) + 1e-7) (trainer.py:712-714) when
  * normalize != 0.  disp [B,1,h,w]; img [B,Ci,h,w]; loss: device scalar.

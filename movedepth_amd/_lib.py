@@ -41,6 +41,10 @@ SIGNATURES = {
     "md_masked_min_ws_bytes": (_sz, [_i, _i, _i]),
     "md_masked_min_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "md_masked_min_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "md_photo_fwd_ws_bytes": (_sz, [_i, _i, _i, _i]),
+    "md_photo_fwd": (_i, [_vp, _vp, _vp]),
+    "md_photo_bwd_ws_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
+    "md_photo_bwd": (_i, [_vp, _vp, _vp]),
     "md_smooth_ws_bytes": (_sz, [_i, _i, _i]),
     "md_smooth_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "md_smooth_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
@@ -72,6 +76,26 @@ SIGNATURES = {
     "md_kernel_timing_read": (_i, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
                                    ctypes.POINTER(_i)]),
 }
+
+PHOTO_MAX_FRAMES = 4
+PHOTO_MAX_SCALES = 4
+
+
+class PhotoDesc(ctypes.Structure):
+    """md_photo_desc of include/movedepth_hip.h (field for field)."""
+    _fields_ = [
+        ("B", _i), ("H", _i), ("W", _i), ("F", _i), ("S", _i),
+        ("is_disp", _i), ("identity", _i), ("mvs_mode", _i), ("no_ssim", _i),
+        ("ssim_w", _f), ("min_depth", _f), ("max_depth", _f),
+        ("dh", _i * PHOTO_MAX_SCALES), ("dw", _i * PHOTO_MAX_SCALES),
+        ("target", _vp), ("src", _vp * PHOTO_MAX_FRAMES), ("T", _vp * PHOTO_MAX_FRAMES), ("K", _vp), ("invK", _vp),
+        ("dz", _vp * PHOTO_MAX_SCALES), ("ident_min", _vp), ("noise", _vp), ("ext_mask", _vp),
+        ("warped", (_vp * PHOTO_MAX_FRAMES) * PHOTO_MAX_SCALES), ("pix", (_vp * PHOTO_MAX_FRAMES) * PHOTO_MAX_SCALES),
+        ("oob", _vp * PHOTO_MAX_FRAMES), ("depth_out", _vp * PHOTO_MAX_SCALES), ("mn", _vp * PHOTO_MAX_SCALES),
+        ("mask", _vp * PHOTO_MAX_SCALES), ("sel", _vp * PHOTO_MAX_SCALES), ("loss", _vp),
+        ("gloss", _vp * PHOTO_MAX_SCALES), ("d_dz", _vp * PHOTO_MAX_SCALES), ("d_T", _vp * PHOTO_MAX_FRAMES),
+    ]
+
 
 _lib = None
 

@@ -58,7 +58,7 @@ __device__ __forceinline__ CamMats md_load_cam(const float *__restrict__ K, cons
         for (int j = 0; j < 4; ++j) {
             float s = 0.f;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) s += K[i * 4 + k] * T[k * 4 + j];
+            for (int k = 0; k < 4; ++k) s = fmaf(K[i * 4 + k], T[k * 4 + j], s);  // explicit: every kernel forms the same P
             m.P[i * 4 + j] = s;
         }
 #pragma unroll

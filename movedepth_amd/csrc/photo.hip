@@ -1,0 +1,656 @@
+// The photometric chain as ONE forward and ONE backward kernel per group of losses:
+//
+//   disparity pyramid level -> full-resolution depth   (trainer.py:512-514, layers.py:400-409)
+//   -> BackprojectDepth / Project3D / grid_sample(border)  for every source frame   (trainer.py:519-529, 501-507, 575-580)
+//   -> SSIM + L1 reprojection loss per frame            (layers.py:663-677, trainer.py:535-550)
+//   -> min over frames, auto-mask against the identity loss (+ tie-break noise), external masks, masked mean
+//                                                       (trainer.py:687-709 mono, 630-662 MVS, 583-612 fused depth)
+//
+// Round 2 ran this as warp_fwd -> ssim_fwd -> (cat) -> masked_min -> finish per (scale, frame): each warped image was written,
+// re-read by the loss kernel, re-read by its backward, its gradient written and re-read by the warp's backward -- 12 times per
+// training step, 1.67 ms of 13-31 us kernels at 10-15 % of the HBM roofline.  Here the warped pixel goes from the gather
+// straight into LDS, the loss, the minimum and the mask are formed from there, and all scales of one compute_losses call are
+// one launch (grid z = scale x sample).  The warped images are still written once (they are outputs of the reference's
+// generate_images_pred, and the backward reads them instead of re-sampling a two-pixel halo).
+//
+//   forward : tile 32 x 16 pixels + halo 1 (reflection: ReflectionPad2d(1) of the SSIM windows), 256 threads.  Phase 1: every
+//             halo position is back-projected, projected and sampled for each frame -> LDS as float4 (3 channels).  Phase 2: a
+//             thread owns two vertically adjacent pixels and reads 4 x 3 taps per image with ds_read_b128.
+//   backward: tile 32 x 8 + halo 2.  d loss / d pred collapses to three coefficient maps per channel (mu_x, E[x^2], E[xy]; see
+//             ssim.hip), built at halo 1 only where the frame is the selected minimum and the mask is set; the gradient at a
+//             pixel is their reflection-adjoint 3x3 sum, handed in registers to the warp's backward (gradients to depth -- or to
+//             the up-sampled disparity -- and, per workgroup, 12 partial sums of dL/dP per frame).
+//   The disparity gradient is then gathered through the adjoint of the bilinear up-sampling by up_adjoint_kernel (all scales
+//   in one launch); the dL/dP partials are summed in double and turned into dL/dT = K^T dP by a one-block-per-(frame, sample)
+//   finish.  Every reduction is two-stage in a fixed order: results are bit-reproducible.
+#include "md_photo.hpp"
+
+namespace {
+using namespace mdp;
+
+constexpr int MAXF = MD_PHOTO_MAX_FRAMES, MAXS = MD_PHOTO_MAX_SCALES;
+constexpr int FT_W = 32, FT_H = 16, FP_W = FT_W + 2, FP_H = FT_H + 2, FP_N = FP_W * FP_H;  // forward tile, + halo 1
+constexpr int BT_W = 32, BT_H = 8;                                                         // backward tile
+constexpr int B2_W = BT_W + 4, B2_H = BT_H + 4, B2_N = B2_W * B2_H;                        // + halo 2 (images)
+constexpr int B1_W = BT_W + 2, B1_H = BT_H + 2, B1_N = B1_W * B1_H;                        // + halo 1 (coefficients)
+
+__device__ __forceinline__ float f4c(const float4 &v, int c) { return c == 0 ? v.x : (c == 1 ? v.y : v.z); }
+
+struct Sample3 {
+    float v[3];
+};
+
+// grid_sample(border, align_corners=True) of a 3-channel image at the clipped position (the forward of warp.hip)
+__device__ __forceinline__ Sample3 sample_border(const float *__restrict__ img, size_t HW, int W, int H, const Clip &c) {
+    const Tap t = md_make_tap(c.ix, c.iy, W, H);
+    const int x1 = t.x0 + 1, y1 = t.y0 + 1;
+    const bool vx1 = x1 < W, vy1 = y1 < H;  // x0, y0 are in range after clipping
+    const float wx0 = 1.f - t.wx1, wy0 = 1.f - t.wy1;
+    Sample3 o;
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+        const float *im = img + ch * HW;
+        float a = im[t.y0 * W + t.x0] * (wy0 * wx0);
+        if (vx1) a += im[t.y0 * W + x1] * (wy0 * t.wx1);
+        if (vy1) a += im[y1 * W + t.x0] * (t.wy1 * wx0);
+        if (vx1 && vy1) a += im[y1 * W + x1] * (t.wy1 * t.wx1);
+        o.v[ch] = a;
+    }
+    return o;
+}
+
+
+// P = (K T)[:3] of every frame and inv_K[:3,:3], computed once per workgroup (12 F + 9 threads), read back by everyone
+template <int F>
+__device__ __forceinline__ void load_cams(const md_photo_desc &a, int b, float *camS /*[F*12+9]*/, CamMats (&cam)[F]) {
+    const int tid = threadIdx.x;
+    if (tid < 12 * F) {
+        const int f = tid / 12, i = (tid % 12) / 4, j = tid % 4;
+        const float *K = a.K + b * 16, *T = a.T[f] + b * 16;
+        float sum = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sum = fmaf(K[i * 4 + k], T[k * 4 + j], sum);   // as md_load_cam
+        camS[tid] = sum;
+    } else if (tid < 12 * F + 9) {
+        const int k = tid - 12 * F;
+        camS[tid] = a.invK[b * 16 + (k / 3) * 4 + k % 3];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+#pragma unroll
+        for (int k = 0; k < 12; ++k) cam[f].P[k] = camS[f * 12 + k];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) cam[f].iK[k] = camS[F * 12 + k];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+template <int F, bool IDENT>
+__global__ __launch_bounds__(256) void photo_fwd_kernel(const md_photo_desc a, float *__restrict__ ws) {
+    extern __shared__ float4 lds[];
+    float4 *tg = lds;          // target, halo 1
+    float4 *wp = lds + FP_N;   // wp[f * FP_N + i]: prediction of frame f
+    __shared__ float red[4][2];
+    __shared__ float camS[MAXF * 12 + 9];
+    const int tid = threadIdx.x;
+    const int s = blockIdx.z / a.B, b = blockIdx.z % a.B;
+    const int x0 = blockIdx.x * FT_W, y0 = blockIdx.y * FT_H;
+    CamMats cam[F];
+    if (!IDENT) load_cams<F>(a, b, camS, cam);
+    const int H = a.H, W = a.W;
+    const size_t HW = (size_t)H * W;
+    const float *tgt = a.target + (size_t)b * 3 * HW;
+    const float min_disp = 1.f / a.max_depth, max_disp = 1.f / a.min_depth;
+
+    // ---- phase 1: every halo position -> target + F predictions in LDS
+#pragma unroll 1
+    for (int i = tid; i < FP_N; i += 256) {
+        const int cy = i / FP_W, cx = i % FP_W;
+        const int gy = y0 - 1 + cy, gx = x0 - 1 + cx;
+        const int py = clampi(reflect1(gy, H), 0, H - 1), px = clampi(reflect1(gx, W), 0, W - 1);
+        const size_t p = (size_t)py * W + px;
+        tg[i] = make_float4(tgt[p], tgt[HW + p], tgt[2 * HW + p], 0.f);
+        if (IDENT) {
+#pragma unroll
+            for (int f = 0; f < F; ++f) {
+                const float *im = a.src[f] + (size_t)b * 3 * HW;
+                wp[f * FP_N + i] = make_float4(im[p], im[HW + p], im[2 * HW + p], 0.f);
+            }
+        } else {
+            // the pixel this thread also writes the per-pixel outputs of (the interior of the tile, inside the image)
+            const bool own = cy >= 1 && cy <= FT_H && cx >= 1 && cx <= FT_W && gy < H && gx < W;
+            float depth;
+            if (a.is_disp) depth = 1.f / disp_up_sd(a.dz[s] + (size_t)b * a.dh[s] * a.dw[s], a.dh[s], a.dw[s], H, W, py, px, min_disp, max_disp);
+            else depth = a.dz[s][(size_t)b * HW + p];
+            if (own && a.depth_out[s]) a.depth_out[s][(size_t)b * HW + p] = depth;
+#pragma unroll
+            for (int f = 0; f < F; ++f) {
+                float r0, r1, r2;
+                md_ray(cam[f], (float)px, (float)py, r0, r1, r2);
+                const Proj pr = md_project(cam[f], r0, r1, r2, depth, W, H);
+                const Clip c = clip_border(pr.ix, pr.iy, W, H);
+                const Sample3 o = sample_border(a.src[f] + (size_t)b * 3 * HW, HW, W, H, c);
+                wp[f * FP_N + i] = make_float4(o.v[0], o.v[1], o.v[2], 0.f);
+                if (own) {
+                    if (a.warped[s][f]) {
+                        float *w_ = a.warped[s][f] + (size_t)b * 3 * HW + p;
+                        w_[0] = o.v[0]; w_[HW] = o.v[1]; w_[2 * HW] = o.v[2];
+                    }
+                    if (a.pix[s][f]) { float *q = a.pix[s][f] + ((size_t)b * HW + p) * 2; q[0] = pr.gx; q[1] = pr.gy; }
+                    if (s == 0 && a.oob[f])
+                        a.oob[f][(size_t)b * HW + p] = (pr.gx < -1.f || pr.gx > 1.f || pr.gy < -1.f || pr.gy > 1.f) ? 1 : 0;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 2: two vertically adjacent pixels per thread
+    const int tx = tid & 31, rp = tid >> 5;
+    const bool use_ssim = !a.no_ssim;
+    const float ssim_w = a.ssim_w;
+    float lossf[2][F];
+    {
+        // No contraction in this block: the window sums follow the reference's order exactly -- AvgPool2d accumulates the nine
+        // taps row-major in float, over tensors of already-rounded products x*x, x*y (layers.py:663-672) -- because
+        // sigma = E[x^2] - mu^2 cancels to 1e-3 of its terms on smooth images and any other association moves the loss by ~1e-4.
+#pragma clang fp contract(off)
+        // pixel k = 0 uses LDS rows 2rp .. 2rp+2, pixel k = 1 rows 2rp+1 .. 2rp+3; both walk rows and columns in ascending order
+        float muy[2][3], ey2[2][3], yc[2][3];
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) muy[k][c] = ey2[k][c] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int o = (2 * rp + r) * FP_W + tx;
+            const float4 t[3] = {tg[o], tg[o + 1], tg[o + 2]};
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float v = f4c(t[j], c), vv = v * v;
+                    if (r <= 2) { muy[0][c] += v; ey2[0][c] += vv; }
+                    if (r >= 1) { muy[1][c] += v; ey2[1][c] += vv; }
+                    if (j == 1 && r == 1) yc[0][c] = v;
+                    if (j == 1 && r == 2) yc[1][c] = v;
+                }
+        }
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+            const float4 *wf = wp + f * FP_N;
+            float mux[2][3], ex2[2][3], exy[2][3], xc[2][3];
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) mux[k][c] = ex2[k][c] = exy[k][c] = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int o = (2 * rp + r) * FP_W + tx;
+                const float4 xv[3] = {wf[o], wf[o + 1], wf[o + 2]};
+                const float4 t[3] = {tg[o], tg[o + 1], tg[o + 2]};
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const float v = f4c(xv[j], c), vv = v * v, vy = v * f4c(t[j], c);
+                        if (r <= 2) { mux[0][c] += v; ex2[0][c] += vv; exy[0][c] += vy; }
+                        if (r >= 1) { mux[1][c] += v; ex2[1][c] += vv; exy[1][c] += vy; }
+                        if (j == 1 && r == 1) xc[0][c] = v;
+                        if (j == 1 && r == 2) xc[1][c] = v;
+                    }
+            }
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                float l1 = 0.f, ss = 0.f;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    l1 += fabsf(yc[k][c] - xc[k][c]);
+                    if (use_ssim) {
+                        Moments m;
+                        m.mux = mux[k][c] / 9.f; m.ex2 = ex2[k][c] / 9.f; m.exy = exy[k][c] / 9.f;
+                        m.muy = muy[k][c] / 9.f; m.ey2 = ey2[k][c] / 9.f;
+                        const float sv = ssim_from(m, nullptr, nullptr);
+                        ss += fminf(fmaxf(sv, 0.f), 1.f);  // torch.clamp(., 0, 1)
+                    }
+                }
+                l1 /= 3.f;
+                ss /= 3.f;
+                lossf[k][f] = use_ssim ? ssim_w * ss + (1.f - ssim_w) * l1 : l1;
+            }
+        }
+    }
+    float num = 0.f, den = 0.f;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int qy = y0 + 2 * rp + k, qx = x0 + tx;
+        if (qy < H && qx < W) {
+            const size_t q = (size_t)b * HW + (size_t)qy * W + qx;
+            float r = lossf[k][0];
+            int am = 0;
+#pragma unroll
+            for (int f = 1; f < F; ++f)
+                if (lossf[k][f] < r) { r = lossf[k][f]; am = f; }  // torch.min: first index wins ties
+            float m = 1.f;
+            if (!IDENT) {
+                if (a.ident_min && !a.mvs_mode) {
+                    float id = a.ident_min[q];
+                    if (a.noise) id += a.noise[(size_t)s * a.B * HW + q];
+                    m = (r <= id) ? 1.f : 0.f;  // argmin([reproj, identity]) == 0, first index wins ties
+                }
+                if (a.ext_mask) m *= a.ext_mask[q];
+                if (a.mask[s]) a.mask[s][q] = m;
+                if (a.sel[s]) a.sel[s][q] = (unsigned char)(am | (m != 0.f ? 0x80 : 0));
+                num += r * m;
+                den += m;
+            }
+            if (a.mn[s]) a.mn[s][q] = r;
+        }
+    }
+    if (!IDENT) {
+        num = md_wave_sum(num);
+        den = md_wave_sum(den);
+        if ((tid & 63) == 0) { red[tid >> 6][0] = num; red[tid >> 6][1] = den; }
+        __syncthreads();
+        if (tid == 0) {
+            const size_t blk = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+            ws[blk * 2] = red[0][0] + red[1][0] + red[2][0] + red[3][0];
+            ws[blk * 2 + 1] = red[0][1] + red[1][1] + red[2][1] + red[3][1];
+        }
+    }
+}
+
+// loss[s] = sum(min * mask) / (sum(mask) + 1e-7), loss[S + ...]: one block per scale, fixed order, double
+__global__ __launch_bounds__(256) void photo_fwd_finish_kernel(const float *__restrict__ ws, int per_scale, float *__restrict__ loss) {
+    __shared__ double red[4][2];
+    const int s = blockIdx.x;
+    double num = 0.0, den = 0.0;
+    for (int k = threadIdx.x; k < per_scale; k += 256) {
+        num += (double)ws[((size_t)s * per_scale + k) * 2];
+        den += (double)ws[((size_t)s * per_scale + k) * 2 + 1];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { num += __shfl_xor(num, o, 64); den += __shfl_xor(den, o, 64); }
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = num; red[threadIdx.x >> 6][1] = den; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        num = red[0][0] + red[1][0] + red[2][0] + red[3][0];
+        den = red[0][1] + red[1][1] + red[2][1] + red[3][1];
+        loss[s * 2] = (float)num / ((float)den + 1e-7f);
+        loss[s * 2 + 1] = (float)den;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ backward
+template <int F>
+__global__ __launch_bounds__(256) void photo_bwd_kernel(const md_photo_desc a, float *__restrict__ gup, float *__restrict__ wsP) {
+    extern __shared__ float4 lds[];
+    float4 *tg = lds;                         // target, halo 2
+    float4 *wp = lds + B2_N;                  // wp[f * B2_N + i]: warped frame f, halo 2
+    float4 *cf = lds + (1 + F) * B2_N;        // cf[k * B1_N + i], k = 0..2: coefficient maps A, B, C of the current frame
+    __shared__ double red[4][12];
+    __shared__ float camS[MAXF * 12 + 9];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int s = blockIdx.z / a.B, b = blockIdx.z % a.B;
+    const int x0 = blockIdx.x * BT_W, y0 = blockIdx.y * BT_H;
+    CamMats cam[F];
+    load_cams<F>(a, b, camS, cam);
+    const int H = a.H, W = a.W;
+    const size_t HW = (size_t)H * W;
+    const float min_disp = 1.f / a.max_depth, max_disp = 1.f / a.min_depth;
+    const bool use_ssim = !a.no_ssim && a.ssim_w != 0.f;
+    const float wl1 = a.no_ssim ? 1.f : (1.f - a.ssim_w);
+    // d loss_s / d (min * mask)[p] = gloss_s / (sum(mask) + 1e-7)
+    const float gscale = a.gloss[s] ? a.gloss[s][0] / (a.loss[s * 2 + 1] + 1e-7f) : 0.f;
+    const unsigned char *selb = a.sel[s] + (size_t)b * HW;
+    const int nblk = gridDim.x * gridDim.y, blk = blockIdx.y * gridDim.x + blockIdx.x;
+
+    {
+        const float *tgt = a.target + (size_t)b * 3 * HW;
+#pragma unroll 1
+        for (int i = tid; i < B2_N; i += 256) {
+            const int py = clampi(reflect1(y0 - 2 + i / B2_W, H), 0, H - 1), px = clampi(reflect1(x0 - 2 + i % B2_W, W), 0, W - 1);
+            const size_t p = (size_t)py * W + px;
+            tg[i] = make_float4(tgt[p], tgt[HW + p], tgt[2 * HW + p], 0.f);
+#pragma unroll
+            for (int f = 0; f < F; ++f) {
+                const float *im = a.warped[s][f] + (size_t)b * 3 * HW;
+                wp[f * B2_N + i] = make_float4(im[p], im[HW + p], im[2 * HW + p], 0.f);
+            }
+        }
+    }
+    const int tx = tid % BT_W, ty = tid / BT_W;
+    const int qx = x0 + tx, qy = y0 + ty;
+    const bool qvalid = qx < W && qy < H;
+    const size_t q = (size_t)qy * W + qx;
+    const unsigned char selq = qvalid ? selb[q] : 0;
+    // a fractional external mask scales the gradient; the selection byte only carries mask != 0
+    const float *maskb = a.mask[s] ? a.mask[s] + (size_t)b * HW : nullptr;
+    // geometry of the pixel, shared by the frames
+    float depth = 1.f, sd = 1.f, r0 = 0.f, r1 = 0.f, r2 = 0.f;
+    if (qvalid) {
+        md_ray(cam[0], (float)qx, (float)qy, r0, r1, r2);
+        if (a.is_disp) {
+            sd = disp_up_sd(a.dz[s] + (size_t)b * a.dh[s] * a.dw[s], a.dh[s], a.dw[s], H, W, qy, qx, min_disp, max_disp);
+            depth = 1.f / sd;
+        } else {
+            depth = a.dz[s][(size_t)b * HW + q];
+        }
+    }
+    float d_depth = 0.f;
+    __syncthreads();
+
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+        const float4 *wf = wp + f * B2_N;
+        // ---- coefficient maps at halo 1, only where frame f is the selected minimum and the mask is set
+        if (use_ssim) {
+#pragma unroll 1
+            for (int i = tid; i < B1_N; i += 256) {
+                const int cy = i / B1_W, cx = i % B1_W;
+                const int py = y0 - 1 + cy, px = x0 - 1 + cx;
+                float4 A = make_float4(0.f, 0.f, 0.f, 0.f), Bc = A, Cc = A;
+                if (py >= 0 && py < H && px >= 0 && px < W && selb[(size_t)py * W + px] == (unsigned char)(0x80 | f)) {
+                    const float gs = gscale * (maskb ? maskb[(size_t)py * W + px] : 1.f) * a.ssim_w / 3.f;
+                    float cA[3], cB[3], cC[3];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+#pragma clang fp contract(off)
+                        Moments m = {0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                            for (int dx = 0; dx < 3; ++dx) {
+                                const float xv = f4c(wf[(cy + dy) * B2_W + cx + dx], c), yv = f4c(tg[(cy + dy) * B2_W + cx + dx], c);
+                                m.mux += xv; m.muy += yv; m.ex2 += xv * xv; m.ey2 += yv * yv; m.exy += xv * yv;
+                            }
+                        m.mux /= 9.f; m.muy /= 9.f; m.ex2 /= 9.f; m.ey2 /= 9.f; m.exy /= 9.f;
+                        ssim_coeffs(m, gs, cA[c], cB[c], cC[c]);
+                    }
+                    A = make_float4(cA[0], cA[1], cA[2], 0.f);
+                    Bc = make_float4(cB[0], cB[1], cB[2], 0.f);
+                    Cc = make_float4(cC[0], cC[1], cC[2], 0.f);
+                }
+                cf[i] = A; cf[B1_N + i] = Bc; cf[2 * B1_N + i] = Cc;
+            }
+            __syncthreads();
+        }
+        double dP[12];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) dP[k] = 0.0;
+        if (qvalid) {
+            // ---- d loss / d pred_f[q][c]
+            float gA[3] = {0.f, 0.f, 0.f}, gB[3] = {0.f, 0.f, 0.f}, gC[3] = {0.f, 0.f, 0.f};
+            if (use_ssim) {
+#pragma unroll
+                for (int dy = -1; dy <= 1; ++dy) {
+                    const int py = qy + dy;
+                    if (py < 0 || py >= H) continue;
+                    // ReflectionPad2d adjoint: row 1 is also pad row -1 (seen by window row 0), row H-2 also pad row H
+                    const float wy = 1.f + ((qy == 1 && py == 0) ? 1.f : 0.f) + ((qy == H - 2 && py == H - 1) ? 1.f : 0.f);
+#pragma unroll
+                    for (int dx = -1; dx <= 1; ++dx) {
+                        const int px = qx + dx;
+                        if (px < 0 || px >= W) continue;
+                        const float wx = 1.f + ((qx == 1 && px == 0) ? 1.f : 0.f) + ((qx == W - 2 && px == W - 1) ? 1.f : 0.f);
+                        const int o = (ty + 1 + dy) * B1_W + tx + 1 + dx;
+                        const float4 A = cf[o], Bc = cf[B1_N + o], Cc = cf[2 * B1_N + o];
+                        const float wgt = wy * wx;
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) { gA[c] += wgt * f4c(A, c); gB[c] += wgt * f4c(Bc, c); gC[c] += wgt * f4c(Cc, c); }
+                    }
+                }
+            }
+            const float4 xq4 = wf[(ty + 2) * B2_W + tx + 2], yq4 = tg[(ty + 2) * B2_W + tx + 2];
+            const float gl1 = (selq == (unsigned char)(0x80 | f)) ? gscale * (maskb ? maskb[q] : 1.f) * wl1 / 3.f : 0.f;
+            float dpred[3];
+            bool any = false;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float xq = f4c(xq4, c), yq = f4c(yq4, c);
+                const float diff = yq - xq;
+                const float sg = diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f);
+                float g = -sg * gl1;
+                if (use_ssim) g += (gA[c] + 2.f * gB[c] * xq + gC[c] * yq) / 9.f;
+                dpred[c] = g;
+                any |= g != 0.f;
+            }
+            // ---- the warp's backward at q (warp.hip): gradients to the depth and to P = (K T)[:3]
+            if (any) {
+                const Proj pr = md_project(cam[f], r0, r1, r2, depth, W, H);
+                const Clip c = clip_border(pr.ix, pr.iy, W, H);
+                const Tap t = md_make_tap(c.ix, c.iy, W, H);
+                const int x1 = t.x0 + 1, y1 = t.y0 + 1;
+                const bool vx1 = x1 < W, vy1 = y1 < H;
+                const float wx0 = 1.f - t.wx1, wy0 = 1.f - t.wy1;
+                float gix = 0.f, giy = 0.f;
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) {
+                    const float *im = a.src[f] + ((size_t)b * 3 + ch) * HW;
+                    const float nw = im[t.y0 * W + t.x0];
+                    const float ne = vx1 ? im[t.y0 * W + x1] : 0.f;
+                    const float sw = vy1 ? im[y1 * W + t.x0] : 0.f;
+                    const float se = (vx1 && vy1) ? im[y1 * W + x1] : 0.f;
+                    gix += dpred[ch] * ((ne - nw) * wy0 + (se - sw) * t.wy1);
+                    giy += dpred[ch] * ((sw - nw) * wx0 + (se - ne) * t.wx1);
+                }
+                const float du = gix * c.gmx * (2.f / (float)(W - 1));
+                const float dv = giy * c.gmy * (2.f / (float)(H - 1));
+                const float dc0 = du / pr.zz, dc1 = dv / pr.zz, dc2 = -(du * pr.u + dv * pr.v) / pr.zz;
+                const float a0 = cam[f].P[0] * r0 + cam[f].P[1] * r1 + cam[f].P[2] * r2;
+                const float a1 = cam[f].P[4] * r0 + cam[f].P[5] * r1 + cam[f].P[6] * r2;
+                const float a2 = cam[f].P[8] * r0 + cam[f].P[9] * r1 + cam[f].P[10] * r2;
+                d_depth += dc0 * a0 + dc1 * a1 + dc2 * a2;
+                if (a.d_T[f]) {
+                    const float Xh[4] = {pr.X, pr.Y, pr.Z, 1.f}, dc[3] = {dc0, dc1, dc2};
+#pragma unroll
+                    for (int i = 0; i < 3; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) dP[i * 4 + j] = (double)(dc[i] * Xh[j]);
+                }
+            }
+        }
+        if (a.d_T[f]) {
+            // per-workgroup partial sums of dL/dP, in double: the terms cancel to ~1 % of their absolute sum
+#pragma unroll
+            for (int k = 0; k < 12; ++k) {
+                double v = dP[k];
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+                if (lane == 0) red[wave][k] = v;
+            }
+            __syncthreads();
+            if (tid < 12)
+                wsP[((((size_t)s * F + f) * a.B + b) * nblk + blk) * 12 + tid] =
+                    (float)(red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid]);
+        }
+        __syncthreads();  // cf / red are reused by the next frame
+    }
+    if (qvalid) {
+        if (a.is_disp) gup[((size_t)s * a.B + b) * HW + q] = -d_depth * (max_disp - min_disp) / (sd * sd);  // d depth / d v = -(max-min)/sd^2
+        else a.d_dz[s][(size_t)b * HW + q] = d_depth;
+    }
+}
+
+// dL/dT[f][b] = K[b][:3,:]^T  sum_{scales, workgroups} dP   (fixed order, double)
+__global__ __launch_bounds__(256) void photo_bwd_finish_kernel(const md_photo_desc a, const float *__restrict__ wsP, int nblk) {
+    __shared__ double red[4][12];
+    __shared__ double dP[12];
+    const int b = blockIdx.x, f = blockIdx.y;
+    if (!a.d_T[f]) return;
+    double acc[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) acc[i] = 0.0;
+    for (int s = 0; s < a.S; ++s) {
+        const float *base = wsP + ((((size_t)s * a.F + f) * a.B + b) * nblk) * 12;
+        for (int k = threadIdx.x; k < nblk; k += 256)
+#pragma unroll
+            for (int i = 0; i < 12; ++i) acc[i] += (double)base[(size_t)k * 12 + i];
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+        double v = acc[i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (lane == 0) red[wave][i] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 12) dP[threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        const int k = threadIdx.x / 4, j = threadIdx.x % 4;
+        double sum = 0.0;
+        for (int i = 0; i < 3; ++i) sum += (double)a.K[b * 16 + i * 4 + k] * dP[i * 4 + j];
+        a.d_T[f][b * 16 + threadIdx.x] = (float)sum;
+    }
+}
+
+// Adjoint of F.interpolate(bilinear, align_corners=False) for every scale in one launch (gather form: deterministic).
+// gup [S][B][H][W]: gradient w.r.t. the up-sampled disparity; d_dz[s] [B,1,dh,dw].  lpp lanes per low-resolution pixel scan the
+// full-resolution pixels whose two source taps can include it: for an r-fold up-sampling, rows r*i - r/2 - 1 ... r*i + 3r/2
+// (the window of (3r+3)^2 used by md_disp_to_depth_up_bwd covers non-integer ratios; here 2r+2 suffices when H % h == 0).
+__global__ __launch_bounds__(256) void up_adjoint_kernel(const md_photo_desc a, const float *__restrict__ gup) {
+    const int s = blockIdx.y;
+    const int h = a.dh[s], w = a.dw[s], H = a.H, W = a.W;
+    const int ry = (H + h - 1) / h, rx = (W + w - 1) / w;
+    int lpp = ry * rx;
+    lpp = lpp >= 64 ? 64 : (lpp >= 16 ? 16 : (lpp >= 4 ? 4 : 1));
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long pixl = gid / lpp;
+    const int sub = (int)(gid % lpp);
+    const bool live = pixl < (long long)a.B * h * w;
+    float acc = 0.f;
+    int b = 0, iy = 0, ix = 0;
+    if (live) {
+        b = (int)(pixl / ((long long)h * w));
+        const int rem = (int)(pixl - (long long)b * h * w);
+        iy = rem / w;
+        ix = rem - iy * w;
+        const bool exact = H % h == 0 && W % w == 0;
+        int oy_lo, oy_hi, ox_lo, ox_hi;
+        if (exact) {
+            oy_lo = max(0, ry * iy - ry / 2 - 1); oy_hi = min(H - 1, ry * iy + (3 * ry) / 2 + 1);
+            ox_lo = max(0, rx * ix - rx / 2 - 1); ox_hi = min(W - 1, rx * ix + (3 * rx) / 2 + 1);
+        } else {
+            const float fy = (float)H / (float)h, fx = (float)W / (float)w;
+            oy_lo = max(0, (int)floorf(((float)iy - 1.f) * fy) - 1); oy_hi = min(H - 1, (int)ceilf(((float)iy + 2.f) * fy) + 1);
+            ox_lo = max(0, (int)floorf(((float)ix - 1.f) * fx) - 1); ox_hi = min(W - 1, (int)ceilf(((float)ix + 2.f) * fx) + 1);
+        }
+        const int fw = ox_hi - ox_lo + 1, n = fw * (oy_hi - oy_lo + 1);
+        const float *g = gup + ((size_t)s * a.B + b) * H * W;
+        for (int k = sub; k < n; k += lpp) {
+            const int oy = oy_lo + k / fw, ox = ox_lo + k % fw;
+            int y0, y1; float ly;
+            interp_idx(oy, h, H, y0, y1, ly);
+            const float wy = (y0 == iy ? 1.f - ly : 0.f) + (y1 == iy ? ly : 0.f);
+            if (wy == 0.f) continue;
+            int x0, x1; float lx;
+            interp_idx(ox, w, W, x0, x1, lx);
+            const float wx = (x0 == ix ? 1.f - lx : 0.f) + (x1 == ix ? lx : 0.f);
+            if (wx == 0.f) continue;
+            acc += g[(size_t)oy * W + ox] * wy * wx;
+        }
+    }
+    for (int o = 1; o < lpp; o <<= 1) acc += __shfl_xor(acc, o, 64);  // fixed tree: deterministic
+    if (live && sub == 0) a.d_dz[s][((size_t)b * h + iy) * w + ix] = acc;
+}
+
+int check_desc(const char *fn, const md_photo_desc *d) {
+    MD_REQUIRE(d, "%s: null descriptor", fn);
+    MD_REQUIRE(d->B > 0 && d->B <= 4096 && d->H >= 3 && d->W >= 3, "%s: bad dims B=%d H=%d W=%d (H, W >= 3)", fn, d->B, d->H, d->W);
+    MD_REQUIRE(d->F >= 1 && d->F <= MAXF && d->S >= 1 && d->S <= MAXS, "%s: F=%d (1..%d), S=%d (1..%d)", fn, d->F, MAXF, d->S, MAXS);
+    MD_REQUIRE((long long)d->B * d->S <= 65535, "%s: B*S too large", fn);
+    MD_REQUIRE(d->target, "%s: null target", fn);
+    for (int f = 0; f < d->F; ++f) MD_REQUIRE(d->src[f], "%s: null src[%d]", fn, f);
+    if (!d->identity) {
+        MD_REQUIRE(d->K && d->invK, "%s: null K / invK", fn);
+        for (int f = 0; f < d->F; ++f) MD_REQUIRE(d->T[f], "%s: null T[%d]", fn, f);
+        for (int s = 0; s < d->S; ++s) {
+            MD_REQUIRE(d->dz[s], "%s: null dz[%d]", fn, s);
+            if (d->is_disp) MD_REQUIRE(d->dh[s] > 0 && d->dw[s] > 0, "%s: bad disparity size at scale %d", fn, s);
+        }
+        MD_REQUIRE(d->min_depth > 0.f && d->max_depth > d->min_depth, "%s: bad depth range", fn);
+    }
+    return MD_OK;
+}
+
+}  // namespace
+
+extern "C" size_t md_photo_fwd_ws_bytes(int B, int S, int H, int W) {
+    return sizeof(float) * 2 * (size_t)B * S * md_cdiv(W, FT_W) * md_cdiv(H, FT_H);
+}
+
+extern "C" int md_photo_fwd(const md_photo_desc *d, void *ws, md_stream_t stream) {
+    int rc = check_desc("md_photo_fwd", d);
+    if (rc) return rc;
+    const int S = d->identity ? 1 : d->S, F = d->F;
+    if (!d->identity) {
+        MD_REQUIRE(ws && d->loss, "md_photo_fwd: null workspace / loss");
+    } else {
+        MD_REQUIRE(d->mn[0], "md_photo_fwd: identity mode writes mn[0]");
+    }
+    dim3 grid(md_cdiv(d->W, FT_W), md_cdiv(d->H, FT_H), d->B * S);
+    const size_t lds = sizeof(float4) * (size_t)(1 + F) * FP_N;
+    hipStream_t st = (hipStream_t)stream;
+#define MD_PH_FWD(F_)                                                                                                       \
+    do {                                                                                                                    \
+        if (d->identity) hipLaunchKernelGGL((photo_fwd_kernel<F_, true>), grid, dim3(256), lds, st, *d, (float *)ws);       \
+        else hipLaunchKernelGGL((photo_fwd_kernel<F_, false>), grid, dim3(256), lds, st, *d, (float *)ws);                  \
+    } while (0)
+    if (F == 1) MD_PH_FWD(1); else if (F == 2) MD_PH_FWD(2); else if (F == 3) MD_PH_FWD(3); else MD_PH_FWD(4);
+#undef MD_PH_FWD
+    MD_CHECK_LAUNCH("md_photo_fwd");
+    if (!d->identity) {
+        hipLaunchKernelGGL(photo_fwd_finish_kernel, dim3(S), dim3(256), 0, st, (const float *)ws, (int)(grid.x * grid.y * d->B), d->loss);
+        MD_CHECK_LAUNCH("md_photo_fwd(finish)");
+    }
+    return MD_OK;
+}
+
+extern "C" size_t md_photo_bwd_ws_bytes(int B, int S, int F, int H, int W, int is_disp) {
+    const size_t parts = (size_t)12 * S * F * B * md_cdiv(W, BT_W) * md_cdiv(H, BT_H);
+    return sizeof(float) * (parts + (is_disp ? (size_t)S * B * H * W : 0));
+}
+
+extern "C" int md_photo_bwd(const md_photo_desc *d, void *ws, md_stream_t stream) {
+    int rc = check_desc("md_photo_bwd", d);
+    if (rc) return rc;
+    MD_REQUIRE(!d->identity, "md_photo_bwd: the identity loss has no gradient path (its inputs are the input frames)");
+    MD_REQUIRE(ws && d->loss, "md_photo_bwd: null workspace / loss");
+    for (int s = 0; s < d->S; ++s) {
+        MD_REQUIRE(d->sel[s] && d->d_dz[s], "md_photo_bwd: null sel / d_dz at scale %d", s);
+        for (int f = 0; f < d->F; ++f) MD_REQUIRE(d->warped[s][f], "md_photo_bwd: the forward's warped[%d][%d] is required", s, f);
+    }
+    const int F = d->F;
+    dim3 grid(md_cdiv(d->W, BT_W), md_cdiv(d->H, BT_H), d->B * d->S);
+    const int nblk = grid.x * grid.y;
+    float *wsP = (float *)ws;
+    float *gup = wsP + (size_t)12 * d->S * F * d->B * nblk;
+    const size_t lds = sizeof(float4) * ((size_t)(1 + F) * B2_N + 3 * B1_N);
+    hipStream_t st = (hipStream_t)stream;
+    if (F == 1) hipLaunchKernelGGL((photo_bwd_kernel<1>), grid, dim3(256), lds, st, *d, gup, wsP);
+    else if (F == 2) hipLaunchKernelGGL((photo_bwd_kernel<2>), grid, dim3(256), lds, st, *d, gup, wsP);
+    else if (F == 3) hipLaunchKernelGGL((photo_bwd_kernel<3>), grid, dim3(256), lds, st, *d, gup, wsP);
+    else hipLaunchKernelGGL((photo_bwd_kernel<4>), grid, dim3(256), lds, st, *d, gup, wsP);
+    MD_CHECK_LAUNCH("md_photo_bwd");
+    bool any_T = false;
+    for (int f = 0; f < F; ++f) any_T |= d->d_T[f] != nullptr;
+    if (any_T) {
+        hipLaunchKernelGGL(photo_bwd_finish_kernel, dim3(d->B, F), dim3(256), 0, st, *d, (const float *)wsP, nblk);
+        MD_CHECK_LAUNCH("md_photo_bwd(finish)");
+    }
+    if (d->is_disp) {
+        long long mx = 0;
+        for (int s = 0; s < d->S; ++s) {
+            int lpp = md_cdiv(d->H, d->dh[s]) * md_cdiv(d->W, d->dw[s]);
+            lpp = lpp >= 64 ? 64 : (lpp >= 16 ? 16 : (lpp >= 4 ? 4 : 1));
+            const long long n = (long long)d->B * d->dh[s] * d->dw[s] * lpp;
+            mx = n > mx ? n : mx;
+        }
+        hipLaunchKernelGGL(up_adjoint_kernel, dim3((unsigned)md_cdiv(mx, 256), d->S), dim3(256), 0, st, *d, (const float *)gup);
+        MD_CHECK_LAUNCH("md_photo_bwd(up-sampling adjoint)");
+    }
+    return MD_OK;
+}

@@ -9,30 +9,14 @@
 //             E[xy]); the gradient at q is then a reflection-adjoint 3x3 box sum of the coefficient maps:
 //             d_pred[q] = (boxT(A) + 2 x_q boxT(B) + y_q boxT(C))[q] / 9 + L1 term.  One 32x8 tile per block,
 //             coefficients staged in LDS (halo 1), inputs staged with halo 2.
-#include "md_common.hpp"
+#include "md_photo.hpp"
 
 namespace {
 
-constexpr float kC1 = 0.01f * 0.01f;
-constexpr float kC2 = 0.03f * 0.03f;
+using namespace mdp;
 constexpr int RY = 8;  // rows per wave strip
 
-__device__ __forceinline__ int reflect1(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
-__device__ __forceinline__ int clampi(int i, int lo, int hi) { return i < lo ? lo : (i > hi ? hi : i); }
-
 __device__ __forceinline__ float hsum3(float v) { return __shfl_up(v, 1, 64) + v + __shfl_down(v, 1, 64); }
-
-struct Moments {
-    float mux, muy, ex2, ey2, exy;
-};
-
-__device__ __forceinline__ float ssim_from(const Moments &m, float *n_out, float *d_out) {
-    const float sx = m.ex2 - m.mux * m.mux, sy = m.ey2 - m.muy * m.muy, sxy = m.exy - m.mux * m.muy;
-    const float n = (2.f * m.mux * m.muy + kC1) * (2.f * sxy + kC2);
-    const float d = (m.mux * m.mux + m.muy * m.muy + kC1) * (sx + sy + kC2);
-    if (n_out) { *n_out = n; *d_out = d; }
-    return (1.f - n / d) / 2.f;
-}
 
 // MODE 0: SSIM map per channel (out [B,C,H,W]);  MODE 1: reprojection loss (out [B,1,H,W]).
 template <int MODE, int C>

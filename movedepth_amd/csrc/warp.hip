@@ -7,26 +7,11 @@
 //
 // Images are 4.4 MB at 192x640xB6: L2-resident, launch-latency-bound.  One thread per target pixel, lanes
 // along x so the source taps of a wave are neighbouring columns (coalesced gathers).
-#include "md_common.hpp"
+#include "md_photo.hpp"
 
 namespace {
 
-struct Clip {
-    float ix, iy, gmx, gmy;
-};
-
-// grid_sample 'border': clip to [0, size-1]; the borders themselves count as clipped (zero grid gradient)
-__device__ __forceinline__ Clip clip_border(float ix, float iy, int W, int H) {
-    Clip c;
-    c.gmx = (float)(W - 1) / 2.f;
-    c.gmy = (float)(H - 1) / 2.f;
-    if (!(ix > 0.f)) { ix = 0.f; c.gmx = 0.f; }
-    else if (ix >= (float)(W - 1)) { ix = (float)(W - 1); c.gmx = 0.f; }
-    if (!(iy > 0.f)) { iy = 0.f; c.gmy = 0.f; }
-    else if (iy >= (float)(H - 1)) { iy = (float)(H - 1); c.gmy = 0.f; }
-    c.ix = ix; c.iy = iy;
-    return c;
-}
+using namespace mdp;
 
 __global__ __launch_bounds__(256) void warp_fwd_kernel(const float *__restrict__ img, const float *__restrict__ depth,
                                                        const float *__restrict__ K, const float *__restrict__ invK,
@@ -153,17 +138,6 @@ __global__ __launch_bounds__(256) void warp_bwd_finish_kernel(const float *__res
 }
 
 // ---- disparity pyramid level -> full-resolution depth
-__device__ __forceinline__ void interp_idx(int o, int in, int out, int &i0, int &i1, float &l1) {
-    const float scale = (float)in / (float)out;
-    float s = scale * ((float)o + 0.5f) - 0.5f;
-    if (s < 0.f) s = 0.f;
-    int a = (int)s;
-    if (a > in - 1) a = in - 1;
-    i0 = a;
-    i1 = a < in - 1 ? a + 1 : a;
-    l1 = s - (float)a;
-}
-
 __global__ __launch_bounds__(256) void disp_up_fwd_kernel(const float *__restrict__ disp, int h, int w, int H, int W,
                                                           float min_disp, float max_disp, float *__restrict__ depth) {
     const int b = blockIdx.z;

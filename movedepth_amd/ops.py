@@ -387,6 +387,167 @@ def masked_min_loss(reproj, ident=None, noise=None, ext_mask=None, mvs_mode=Fals
     return _MaskedMin.apply(reproj, ident, noise, ext_mask, bool(mvs_mode))
 
 
+# --------------------------------------------------------------------------- the photometric chain, fused
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _fill_desc(d, cfg, target, srcs, Ts, K, invK, dzs, ident_min, noise, ext_mask):
+    B, _, H, W = target.shape
+    d.B, d.H, d.W, d.F, d.S = B, H, W, len(srcs), len(dzs)
+    d.is_disp, d.identity, d.mvs_mode, d.no_ssim = int(cfg["is_disp"]), int(cfg["identity"]), int(cfg["mvs_mode"]), int(cfg["no_ssim"])
+    d.ssim_w, d.min_depth, d.max_depth = float(cfg["ssim_w"]), float(cfg["min_depth"]), float(cfg["max_depth"])
+    d.target, d.K, d.invK = _ptr(target), _ptr(K), _ptr(invK)
+    d.ident_min, d.noise, d.ext_mask = _ptr(ident_min), _ptr(noise), _ptr(ext_mask)
+    for f, (im, T) in enumerate(zip(srcs, Ts)):
+        d.src[f], d.T[f] = _ptr(im), _ptr(T)
+    for si, z in enumerate(dzs):
+        if z is None:
+            continue
+        d.dz[si] = _ptr(z)
+        d.dh[si], d.dw[si] = (z.shape[-2], z.shape[-1]) if cfg["is_disp"] else (H, W)
+
+
+class _PhotoLoss(torch.autograd.Function):
+    """md_photo_fwd / md_photo_bwd: one launch each way for all scales and frames of one group of photometric losses."""
+
+    @staticmethod
+    def forward(ctx, cfg, target, K, invK, ident_min, noise, ext_mask, *rest):
+        F, S = cfg["F"], cfg["S"]
+        srcs = [_prep(t, "source frame") for t in rest[:F]]
+        Ts = [_prep(t, "T").reshape(-1, 4, 4) for t in rest[F:2 * F]]
+        dzs = [_prep(t, "disp / depth") for t in rest[2 * F:2 * F + S]]
+        target, K, invK = _prep(target, "target"), _prep(K, "K"), _prep(invK, "inv_K")
+        ident_min, noise, ext_mask = _prep(ident_min, "identity loss"), _prep(noise, "noise"), _prep(ext_mask, "mask")
+        B, Ci, H, W = target.shape
+        if Ci != 3:
+            raise _lib.MovedepthHipError("photometric_loss: images must have 3 channels (got %d)" % Ci)
+        dev, f32 = target.device, torch.float32
+        for z in dzs:
+            if not cfg["is_disp"] and z.numel() != B * H * W:
+                raise RuntimeError("depth has %d elements, expected B*H*W=%d" % (z.numel(), B * H * W))
+        if noise is not None and noise.numel() != S * B * H * W:
+            raise RuntimeError("noise must have S*B*H*W = %d elements (one draw per scale, trainer.py:698)" % (S * B * H * W))
+        d = _lib.PhotoDesc()
+        _fill_desc(d, cfg, target, srcs, Ts, K, invK, dzs, ident_min, noise, ext_mask)
+        warped = torch.empty(S, F, B, 3, H, W, device=dev, dtype=f32)
+        pix = torch.empty(S, F, B, H, W, 2, device=dev, dtype=f32) if cfg["want_pix"] else None
+        oob = torch.empty(F, B, H, W, device=dev, dtype=torch.uint8) if cfg["want_oob"] else None
+        depth_out = torch.empty(S, B, 1, H, W, device=dev, dtype=f32) if cfg["is_disp"] else None
+        mn = torch.empty(S, B, 1, H, W, device=dev, dtype=f32)
+        mask = torch.empty(S, B, 1, H, W, device=dev, dtype=f32) if cfg["want_mask"] else None
+        sel = torch.empty(S, B, H, W, device=dev, dtype=torch.uint8)
+        loss2 = torch.empty(S, 2, device=dev, dtype=f32)
+        for si in range(S):
+            for f in range(F):
+                d.warped[si][f] = warped[si, f].data_ptr()
+                if pix is not None:
+                    d.pix[si][f] = pix[si, f].data_ptr()
+            if depth_out is not None:
+                d.depth_out[si] = depth_out[si].data_ptr()
+            d.mn[si], d.sel[si] = mn[si].data_ptr(), sel[si].data_ptr()
+            if mask is not None:
+                d.mask[si] = mask[si].data_ptr()
+        if oob is not None:
+            for f in range(F):
+                d.oob[f] = oob[f].data_ptr()
+        d.loss = loss2.data_ptr()
+        ws = _ws(_lib.load().md_photo_fwd_ws_bytes(B, S, H, W), dev)
+        _timed_call("md_photo_fwd", ctypes.byref(d), _p(ws), _stream())
+        ctx.cfg = cfg
+        ctx.shapes = [t.shape for t in rest[F:2 * F]], [t.shape for t in rest[2 * F:2 * F + S]]
+        saved = [target, K, invK, warped, sel, loss2] + srcs + Ts + dzs
+        ctx.has_mask = mask is not None and ext_mask is not None
+        if ctx.has_mask:
+            saved.append(mask)
+        ctx.save_for_backward(*saved)
+        ctx.set_materialize_grads(False)
+        aux = [t for t in (warped, pix, oob, depth_out, mn, mask) if t is not None]
+        ctx.mark_non_differentiable(*aux)
+        ctx.n_aux = 6
+        return tuple(loss2[si, 0] for si in range(S)) + (warped, pix, oob, depth_out, mn, mask)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        cfg = ctx.cfg
+        F, S = cfg["F"], cfg["S"]
+        saved = ctx.saved_tensors
+        target, K, invK, warped, sel, loss2 = saved[:6]
+        srcs, Ts, dzs = saved[6:6 + F], saved[6 + F:6 + 2 * F], saved[6 + 2 * F:6 + 2 * F + S]
+        mask = saved[6 + 2 * F + S] if ctx.has_mask else None
+        B, _, H, W = target.shape
+        d = _lib.PhotoDesc()
+        _fill_desc(d, cfg, target, srcs, Ts, K, invK, dzs, None, None, None)
+        gl = [None if g is None else g.reshape(1).contiguous().float() for g in grads[:S]]
+        d_dz = [torch.empty_like(z) for z in dzs]
+        need_T = [ctx.needs_input_grad[7 + F + f] for f in range(F)]
+        d_T = [torch.empty(B, 4, 4, device=target.device, dtype=torch.float32) if need_T[f] else None for f in range(F)]
+        for si in range(S):
+            for f in range(F):
+                d.warped[si][f] = warped[si, f].data_ptr()
+            d.sel[si] = sel[si].data_ptr()
+            if mask is not None:
+                d.mask[si] = mask[si].data_ptr()
+            d.gloss[si] = _ptr(gl[si])
+            d.d_dz[si] = d_dz[si].data_ptr()
+        for f in range(F):
+            d.d_T[f] = _ptr(d_T[f])
+        d.loss = loss2.data_ptr()
+        ws = _ws(_lib.load().md_photo_bwd_ws_bytes(B, S, F, H, W, int(cfg["is_disp"])), target.device)
+        _timed_call("md_photo_bwd", ctypes.byref(d), _p(ws), _stream())
+        t_shapes, z_shapes = ctx.shapes
+        out_T = [None if d_T[f] is None else d_T[f].reshape(t_shapes[f]) for f in range(F)]
+        out_z = [d_dz[si].reshape(z_shapes[si]) if ctx.needs_input_grad[7 + 2 * F + si] else None for si in range(S)]
+        return (None,) * 7 + (None,) * F + tuple(out_T) + tuple(out_z)
+
+
+def photometric_loss(target, srcs, Ts, K, invK, depths, is_disp=False, min_depth=0.1, max_depth=100.0, ssim_w=0.85,
+                     no_ssim=False, ident_min=None, noise=None, ext_mask=None, mvs_mode=False, want_pix=False,
+                     want_oob=False, want_mask=False):
+    """generate_images_pred + compute_losses' photometric part for one group of losses, in one launch each way
+    (reference trainer.py:491-532 with 675-709 [mono, every scale], 498-509 with 621-662 [MVS], 569-612 [fused depth]).
+
+    target (B,3,H,W); srcs: F source frames (B,3,H,W); Ts: F poses (B,4,4); depths: S tensors -- disparity pyramid levels
+    (B,1,h_s,w_s) when is_disp (up-sampled to HxW and converted with min/max_depth inside) or depth maps (B,[1,]H,W).
+    ident_min (B,1,H,W): the identity loss of identity_loss(); noise (S,B,1,H,W): the 1e-5-scaled tie-break noise.
+    Returns a dict: loss (list of S scalars, differentiable w.r.t. depths and Ts), warped[s][f], pix[s][f] | None,
+    oob[f] | None, depth[s] | None (is_disp only), min[s] (B,1,H,W), mask[s] | None."""
+    F, S = len(srcs), len(depths)
+    if not (1 <= F <= _lib.PHOTO_MAX_FRAMES and 1 <= S <= _lib.PHOTO_MAX_SCALES):
+        raise _lib.MovedepthHipError("photometric_loss: %d source frames / %d scales (1..4 each)" % (F, S))
+    cfg = dict(F=F, S=S, is_disp=bool(is_disp), identity=False, mvs_mode=bool(mvs_mode), no_ssim=bool(no_ssim) or ssim_w == 0,
+               ssim_w=float(ssim_w), min_depth=float(min_depth), max_depth=float(max_depth), want_pix=bool(want_pix),
+               want_oob=bool(want_oob), want_mask=bool(want_mask) or ext_mask is not None)
+    out = _PhotoLoss.apply(cfg, target, K, invK, ident_min, noise, ext_mask, *srcs, *Ts, *depths)
+    warped, pix, oob, depth_out, mn, mask = out[S:]
+    return {"loss": list(out[:S]),
+            "warped": [[warped[s, f] for f in range(F)] for s in range(S)],
+            "pix": None if pix is None else [[pix[s, f] for f in range(F)] for s in range(S)],
+            "oob": None if oob is None else [oob[f] for f in range(F)],
+            "depth": None if depth_out is None else [depth_out[s] for s in range(S)],
+            "min": [mn[s] for s in range(S)],
+            "mask": None if mask is None else [mask[s] for s in range(S)]}
+
+
+def identity_loss(target, srcs, ssim_w=0.85, no_ssim=False):
+    """min over frames of compute_reprojection_loss(src_f, target) (reference trainer.py:690-696 / 592-599): the identity
+    loss the auto-mask compares against, evaluated once per step (it does not depend on the scale) -> (B,1,H,W).  no_grad:
+    its inputs are the input frames."""
+    with torch.no_grad():
+        target = _prep(target, "target")
+        srcs = [_prep(t, "source frame") for t in srcs]
+        B, _, H, W = target.shape
+        cfg = dict(is_disp=False, identity=True, mvs_mode=False, no_ssim=bool(no_ssim) or ssim_w == 0, ssim_w=float(ssim_w),
+                   min_depth=0.1, max_depth=100.0)
+        d = _lib.PhotoDesc()
+        _fill_desc(d, cfg, target, srcs, [None] * len(srcs), None, None, [None], None, None, None)
+        d.S = 1
+        out = torch.empty(B, 1, H, W, device=target.device, dtype=torch.float32)
+        d.mn[0] = out.data_ptr()
+        _timed_call("md_photo_fwd", ctypes.byref(d), None, _stream())
+    return out
+
+
 # --------------------------------------------------------------------------- smoothness
 class _Smooth(torch.autograd.Function):
     @staticmethod

@@ -104,6 +104,9 @@ class MonodepthOptions:
         p.add_argument("--hip_bn_relu", type=int, default=1,
                        help="the 3-D regulariser's two full-resolution BatchNorm+ReLU (+skip add) on the fused kernels "
                             "(47.8 vs 49.1 ms per step; 0: library BatchNorm + torch ops)")
+        p.add_argument("--fused_photometric", type=int, default=1,
+                       help="generate_images_pred + compute_losses' photometric part as one kernel launch each way per group of "
+                            "losses (csrc/photo.hip); 0: one kernel per warp / loss / reduction, as in round 2")
         p.add_argument("--amp", default="none", choices=["none", "bf16", "fp16"],
                        help="mixed precision (BASELINE configs 4 / 5): networks under autocast, 2-byte cost volume; the "
                             "headline bench is fp32")

@@ -365,6 +365,8 @@ class Trainer:
         """Warp the neighbouring frames into the reference view (reference trainer.py:491-532)."""
         opt = self.opt
         K, inv_K = inputs[("K", 0)], inputs[("inv_K", 0)]
+        if opt.fused_photometric:
+            return self._generate_images_pred_fused(inputs, outputs, is_mvs)
         if is_mvs:
             depth_mvs = outputs["depth_mvs"]
             for frame_id in opt.frame_ids[1:]:
@@ -383,6 +385,49 @@ class Trainer:
                 outputs[("color", frame_id, scale)] = warped
                 outputs[("color_identity", frame_id, scale)] = inputs[("color", frame_id, 0)]
 
+    def _generate_images_pred_fused(self, inputs, outputs, is_mvs):
+        """generate_images_pred with the losses of the following compute_losses call formed in the same launch
+        (ops.photometric_loss: warps of every frame and scale + SSIM/L1 + min over frames + auto-mask + masked mean).  Fills
+        the same `outputs` entries; the loss scalars wait under a private key for compute_losses.  The warped images it
+        stores are outputs, not graph nodes: gradients flow through the stashed losses."""
+        opt = self.opt
+        K, inv_K = inputs[("K", 0)], inputs[("inv_K", 0)]
+        target = inputs[("color", 0, 0)]
+        frames = opt.frame_ids[1:]
+        srcs = [inputs[("color", f, 0)] for f in frames]
+        B, _, H, W = target.shape
+        common = dict(min_depth=opt.min_depth, max_depth=opt.max_depth, ssim_w=opt.ssim_lw, no_ssim=opt.no_ssim)
+        if is_mvs:
+            ext = None
+            if opt.mask_mvs_conf:
+                ext = outputs["photo_conf_map"].float()
+            if opt.mask_mvs_dist:
+                ext = outputs["dist_mask"].float() if ext is None else ext * outputs["dist_mask"].float()
+            if opt.mask_mvs_geo:
+                for f_id in frames:
+                    ext = outputs[("geo_mask", f_id)] if ext is None else ext * outputs[("geo_mask", f_id)]  # KeyError upstream too
+            res = ops.photometric_loss(target, srcs, [outputs[("cam_T_cam", 0, f)].detach() for f in frames], K, inv_K,
+                                       [outputs["depth_mvs"]], mvs_mode=True, ext_mask=ext, want_oob=True, want_mask=True, **common)
+            for i, f in enumerate(frames):
+                outputs[("mvs_mask", f)] = res["oob"][i].bool()
+                outputs[("mvs_color", f)] = res["warped"][0][i]
+            outputs[("_photo", "mvs")] = res
+            return
+        ident = noise = None
+        if not opt.disable_automasking:
+            ident = ops.identity_loss(target, srcs, opt.ssim_lw, opt.no_ssim)
+            noise = self._automask_noise((B, 1, H, W), len(opt.scales))   # one draw per scale, in the reference's order
+        res = ops.photometric_loss(target, srcs, [outputs[("cam_T_cam", 0, f)] for f in frames], K, inv_K,
+                                   [outputs[("disp", s)] for s in opt.scales], is_disp=True, ident_min=ident, noise=noise,
+                                   want_pix=True, **common)
+        for si, scale in enumerate(opt.scales):
+            outputs[("depth", 0, scale)] = res["depth"][si]
+            for i, f in enumerate(frames):
+                outputs[("sample", f, scale)] = res["pix"][si][i]
+                outputs[("color", f, scale)] = res["warped"][si][i]
+                outputs[("color_identity", f, scale)] = inputs[("color", f, 0)]
+        outputs[("_photo", "mono")] = res
+
     def compute_reprojection_loss(self, pred, target, ssim_lw=None):
         """SSIM + L1 photometric loss (reference trainer.py:535-550) -> (B,1,H,W)."""
         w = self.opt.ssim_lw if ssim_lw is None else ssim_lw
@@ -397,11 +442,15 @@ class Trainer:
         all_losses = torch.cat([reprojection_loss, identity_reprojection_loss], dim=1)
         return (torch.argmin(all_losses, dim=1, keepdim=True) == 0).float()
 
-    def _automask_noise(self, shape):
-        """The reference's tie-break: identity += randn(shape) * 1e-5 (trainer.py:698)."""
+    def _automask_noise(self, shape, count=None):
+        """The reference's tie-break: identity += randn(shape) * 1e-5 (trainer.py:698).  count: that many consecutive draws
+        stacked (host mode: the same draws, in the same order, as `count` calls)."""
         if self.opt.automask_noise == "host":
-            return (torch.randn(shape) * 0.00001).to(self.device)
-        return torch.randn(shape, device=self.device) * 0.00001
+            if count is None:
+                return (torch.randn(shape) * 0.00001).to(self.device)
+            return torch.stack([torch.randn(shape) * 0.00001 for _ in range(count)]).to(self.device)
+        full = shape if count is None else (count,) + tuple(shape)
+        return torch.randn(full, device=self.device) * 0.00001
 
     def _identity_losses(self, inputs, ssim_lw=None):
         target = inputs[("color", 0, 0)]
@@ -414,6 +463,20 @@ class Trainer:
         depth_fuse = outputs["fused_depth"]
         K, inv_K = inputs[("K", 0)], inputs[("inv_K", 0)]
         target = inputs[("color", 0, 0)]
+        if opt.fused_photometric:
+            frames = opt.frame_ids[1:]
+            srcs = [inputs[("color", f, 0)] for f in frames]
+            ident = noise = None
+            if opt.mask_mvs_auto:
+                ident = ops.identity_loss(target, srcs, 0.0, True)
+                noise = self._automask_noise((target.shape[0], 1) + tuple(target.shape[2:]), 1)
+            res = ops.photometric_loss(target, srcs, [outputs[("cam_T_cam", 0, f)].detach() for f in frames], K, inv_K,
+                                       [depth_fuse], min_depth=opt.min_depth, max_depth=opt.max_depth, ssim_w=0.0, no_ssim=True,
+                                       ident_min=ident, noise=noise, want_mask=True)
+            for i, f in enumerate(frames):
+                outputs[("mvs_color_fuse", f)] = res["warped"][0][i]
+            outputs["reprojection_loss_mask"] = res["mask"][0]
+            return {"fuse_reproj_loss": res["loss"][0], "loss": res["loss"][0]}
         reprojection_losses = []
         for frame_id in opt.frame_ids[1:]:
             T = outputs[("cam_T_cam", 0, frame_id)].detach()
@@ -437,6 +500,20 @@ class Trainer:
         target = inputs[("color", 0, 0)]
         B, _, H, W = target.shape
 
+        fused = outputs.get(("_photo", "mvs" if is_mvs else "mono")) if opt.fused_photometric else None
+        if is_mvs and fused is not None:
+            if opt.mask_mvs_auto:
+                self._automask_noise((B, 1, H, W))  # drawn and discarded upstream: the mask is overwritten (App. B-4)
+            loss = fused["loss"][0]
+            outputs["mvs_reprojection_loss"] = fused["min"][0]
+            outputs["reprojection_loss_mask"] = fused["mask"][0]
+            outputs["mvs_reproj_loss"] = loss
+            if opt.mvs_smooth_loss:
+                smooth_loss = ops.smooth_loss(outputs["depth_mvs"].unsqueeze(1), inputs[("color", 0, 0)], normalize=True)
+                losses["mvs_smooth_loss/0"] = smooth_loss
+                loss = loss + opt.disparity_smoothness * smooth_loss
+            losses["loss"] = loss
+            return losses
         if is_mvs:
             reprojection_losses = torch.cat([self.compute_reprojection_loss(outputs[("mvs_color", f)], target)
                                              for f in opt.frame_ids[1:]], 1)
@@ -461,15 +538,18 @@ class Trainer:
             losses["loss"] = loss
             return losses
 
-        ident = None if opt.disable_automasking else self._identity_losses(inputs)  # same values at every scale
+        ident = None if (opt.disable_automasking or fused is not None) else self._identity_losses(inputs)  # same values at every scale
         total_loss = 0
-        for scale in opt.scales:
-            reprojection_losses = torch.cat([self.compute_reprojection_loss(outputs[("color", f, scale)], target)
-                                             for f in opt.frame_ids[1:]], 1)
-            if ident is not None:
-                loss, min_reproj, _ = ops.masked_min_loss(reprojection_losses, ident, self._automask_noise((B, 1, H, W)))
+        for si, scale in enumerate(opt.scales):
+            if fused is not None:   # formed by generate_images_pred's launch
+                loss, min_reproj = fused["loss"][si], fused["min"][si]
             else:
-                loss, min_reproj, _ = ops.masked_min_loss(reprojection_losses)
+                reprojection_losses = torch.cat([self.compute_reprojection_loss(outputs[("color", f, scale)], target)
+                                                 for f in opt.frame_ids[1:]], 1)
+                if ident is not None:
+                    loss, min_reproj, _ = ops.masked_min_loss(reprojection_losses, ident, self._automask_noise((B, 1, H, W)))
+                else:
+                    loss, min_reproj, _ = ops.masked_min_loss(reprojection_losses)
             if scale == 0:
                 outputs["mono_reproj_loss"] = min_reproj
             smooth_loss = ops.smooth_loss(outputs[("disp", scale)], inputs[("color", 0, scale)], normalize=True)
