@@ -207,6 +207,18 @@ int md_smooth_fwd(const float *disp, const float *img, int B, int Ci, int h, int
 int md_smooth_bwd(const float *gloss, const float *disp, const float *img, int B, int Ci, int h, int w,
                   int normalize, float *d_disp, void *ws, md_stream_t stream);
 
+/* The same for every disparity pyramid level of one compute_losses call (trainer.py:712-714 inside the scale loop) in one
+ * launch per pass: disp[s] [B,1,h[s],w[s]], img[s] [B,Ci,h[s],w[s]], loss[s]; gloss[s] device scalars (NULL = 0).
+ * ws: md_smooth_multi_ws_bytes(B, S). */
+size_t md_smooth_multi_ws_bytes(int B, int S);
+int md_smooth_multi_fwd(const float *const *disp, const float *const *img, const int *h, const int *w, int S, int B, int Ci,
+                        int normalize, float *loss, void *ws, md_stream_t stream);
+int md_smooth_multi_bwd(const float *const *gloss, const float *const *disp, const float *const *img, const int *h, const int *w,
+                        int S, int B, int Ci, int normalize, float *const *d_disp, void *ws, md_stream_t stream);
+
+/* sizeof(md_photo_desc): lets a binding check its struct layout against the library's */
+size_t md_photo_desc_bytes(void);
+
 /* ---- post-volume ops ("next" rows) --------------------------------------------
  * Fused softmax over D (trainer.py:367) + entropy (layers.py:862-863) + localmax (layers.py:796-812).
  * logits [B,D,h,w]; min_inv, max_inv [B,h,w] (the caller passes 1/hyp[:,-1], 1/hyp[:,0], trainer.py:371).

@@ -45,6 +45,10 @@ SIGNATURES = {
     "md_photo_fwd": (_i, [_vp, _vp, _vp]),
     "md_photo_bwd_ws_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
     "md_photo_bwd": (_i, [_vp, _vp, _vp]),
+    "md_photo_desc_bytes": (_sz, []),
+    "md_smooth_multi_ws_bytes": (_sz, [_i, _i]),
+    "md_smooth_multi_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "md_smooth_multi_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "md_smooth_ws_bytes": (_sz, [_i, _i, _i]),
     "md_smooth_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "md_smooth_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
@@ -123,6 +127,9 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the .so is stale
         fn.restype = res
         fn.argtypes = args
+    if lib.md_photo_desc_bytes() != ctypes.sizeof(PhotoDesc):
+        raise MovedepthHipError("md_photo_desc is %d bytes in the library, %d in the binding: stale build?"
+                                % (lib.md_photo_desc_bytes(), ctypes.sizeof(PhotoDesc)))
     _lib = lib
     return lib
 

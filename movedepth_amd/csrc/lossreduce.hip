@@ -82,14 +82,27 @@ int mm_blocks(int total) {
 
 // ------------------------------------------------------------------ smoothness
 constexpr int SM_BLK = 64;  // blocks per sample for the pixel passes
+constexpr int SM_MAXS = MD_PHOTO_MAX_SCALES;
 
-// workspace layout (floats): (unused)[B] | part[B*SM_BLK*2] | dots[B*SM_BLK] | msum[B*SM_BLK]
+// All pyramid levels of one compute_losses call in one launch per pass (grid z = level): 3 + 3 launches per step instead of
+// 12 + 12 of 4-16 us kernels over 0.03-1.5 MB maps.
+struct SmoothArgs {
+    const float *disp[SM_MAXS], *img[SM_MAXS], *gloss[SM_MAXS];
+    float *d_disp[SM_MAXS];
+    int h[SM_MAXS], w[SM_MAXS];
+    int B, Ci, normalize, S;
+};
+// workspace layout per level (floats): (unused)[B] | part[B*SM_BLK*2] | dots[B*SM_BLK] | msum[B*SM_BLK]
+__host__ __device__ inline size_t sm_ws_floats(int B) { return (size_t)B + (size_t)B * SM_BLK * 4; }
+
 // Mean of each sample's disparity, stage 1: SM_BLK partial sums per sample.  (One block per sample, as this was at
 // first, is 480 dependent loads per thread at 192x640: 186 us for a 0.5 MB reduction.)  Stage 2 is sample_mean() at the
 // top of each consumer, always the same fixed-order sum, so forward and backward see the identical mean.
-__global__ __launch_bounds__(256) void smooth_mean_kernel(const float *__restrict__ disp, int hw, int B, float *__restrict__ ws) {
+__global__ __launch_bounds__(256) void smooth_mean_kernel(const SmoothArgs a, float *__restrict__ wsall) {
     __shared__ float red[4];
-    const int b = blockIdx.y;
+    const int b = blockIdx.y, lv = blockIdx.z, B = a.B, hw = a.h[lv] * a.w[lv];
+    float *ws = wsall + lv * sm_ws_floats(B);
+    const float *disp = a.disp[lv];
     float s = 0.f;
     for (int p = blockIdx.x * 256 + threadIdx.x; p < hw; p += SM_BLK * 256) s += disp[(size_t)b * hw + p];
     s = block_sum(s, red);
@@ -107,18 +120,18 @@ __device__ __forceinline__ float edge_w(const float *__restrict__ img, int Ci, s
     return expf(-gi / (float)Ci);
 }
 
-__global__ __launch_bounds__(256) void smooth_fwd_kernel(const float *__restrict__ disp, const float *__restrict__ img,
-                                                         int Ci, int h, int w, int normalize, int B, float *__restrict__ ws) {
+__global__ __launch_bounds__(256) void smooth_fwd_kernel(const SmoothArgs a, float *__restrict__ wsall) {
     __shared__ float red[4];
-    const int b = blockIdx.y, hw = h * w;
-    const float dn = normalize ? sample_mean(ws, B, b, hw, red) + 1e-7f : 1.f;
-    const float *d = disp + (size_t)b * hw, *im = img + (size_t)b * Ci * hw;
+    const int b = blockIdx.y, lv = blockIdx.z, B = a.B, Ci = a.Ci, h = a.h[lv], w = a.w[lv], hw = h * w;
+    float *ws = wsall + lv * sm_ws_floats(B);
+    const float dn = a.normalize ? sample_mean(ws, B, b, hw, red) + 1e-7f : 1.f;
+    const float *d = a.disp[lv] + (size_t)b * hw, *im = a.img[lv] + (size_t)b * Ci * hw;
     float sx = 0.f, sy = 0.f;
     for (int p = blockIdx.x * 256 + threadIdx.x; p < hw; p += SM_BLK * 256) {
         const int x = p % w, y = p / w;
-        const float a = d[p] / dn;
-        if (x + 1 < w) sx += fabsf(a - d[p + 1] / dn) * edge_w(im, Ci, hw, p, p + 1);
-        if (y + 1 < h) sy += fabsf(a - d[p + w] / dn) * edge_w(im, Ci, hw, p, p + w);
+        const float v = d[p] / dn;
+        if (x + 1 < w) sx += fabsf(v - d[p + 1] / dn) * edge_w(im, Ci, hw, p, p + 1);
+        if (y + 1 < h) sy += fabsf(v - d[p + w] / dn) * edge_w(im, Ci, hw, p, p + w);
     }
     sx = block_sum(sx, red);
     sy = block_sum(sy, red);
@@ -128,33 +141,36 @@ __global__ __launch_bounds__(256) void smooth_fwd_kernel(const float *__restrict
     }
 }
 
-__global__ __launch_bounds__(256) void smooth_finish_kernel(const float *__restrict__ ws, int B, int h, int w, float *__restrict__ loss) {
+__global__ __launch_bounds__(256) void smooth_finish_kernel(const SmoothArgs a, const float *__restrict__ wsall, float *__restrict__ loss) {
     __shared__ float red[4];
+    const int lv = blockIdx.x, B = a.B, h = a.h[lv], w = a.w[lv];
+    const float *ws = wsall + lv * sm_ws_floats(B);
     float sx = 0.f, sy = 0.f;
     for (int k = threadIdx.x; k < B * SM_BLK; k += 256) { sx += ws[B + k * 2]; sy += ws[B + k * 2 + 1]; }
     sx = block_sum(sx, red);
     sy = block_sum(sy, red);
-    if (threadIdx.x == 0) loss[0] = sx / ((float)B * h * (w - 1)) + sy / ((float)B * (h - 1) * w);
+    if (threadIdx.x == 0) loss[lv] = sx / ((float)B * h * (w - 1)) + sy / ((float)B * (h - 1) * w);
 }
 
 // pass 1 of the backward: gn = dL/d(normalised disp) (gather form) into d_disp, and per-block dot(gn, disp)
-__global__ __launch_bounds__(256) void smooth_bwd_kernel(const float *__restrict__ gloss, const float *__restrict__ disp,
-                                                         const float *__restrict__ img, int Ci, int h, int w, int normalize,
-                                                         int B, float *__restrict__ d_disp, float *__restrict__ ws) {
+__global__ __launch_bounds__(256) void smooth_bwd_kernel(const SmoothArgs a, float *__restrict__ wsall) {
     __shared__ float red[4];
-    const int b = blockIdx.y, hw = h * w;
-    const float dn = normalize ? sample_mean(ws, B, b, hw, red) + 1e-7f : 1.f;
-    const float cx = gloss[0] / ((float)B * h * (w - 1)), cy = gloss[0] / ((float)B * (h - 1) * w);
-    const float *d = disp + (size_t)b * hw, *im = img + (size_t)b * Ci * hw;
+    const int b = blockIdx.y, lv = blockIdx.z, B = a.B, Ci = a.Ci, h = a.h[lv], w = a.w[lv], hw = h * w;
+    float *ws = wsall + lv * sm_ws_floats(B);
+    const float dn = a.normalize ? sample_mean(ws, B, b, hw, red) + 1e-7f : 1.f;
+    const float gl = a.gloss[lv] ? a.gloss[lv][0] : 0.f;
+    const float cx = gl / ((float)B * h * (w - 1)), cy = gl / ((float)B * (h - 1) * w);
+    const float *d = a.disp[lv] + (size_t)b * hw, *im = a.img[lv] + (size_t)b * Ci * hw;
+    float *d_disp = a.d_disp[lv];
     float dot = 0.f;
     for (int p = blockIdx.x * 256 + threadIdx.x; p < hw; p += SM_BLK * 256) {
         const int x = p % w, y = p / w;
-        const float a = d[p] / dn;
+        const float v = d[p] / dn;
         float g = 0.f;
-        if (x + 1 < w) { const float df = a - d[p + 1] / dn; g += (df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f)) * edge_w(im, Ci, hw, p, p + 1) * cx; }
-        if (x > 0)     { const float df = d[p - 1] / dn - a; g -= (df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f)) * edge_w(im, Ci, hw, p - 1, p) * cx; }
-        if (y + 1 < h) { const float df = a - d[p + w] / dn; g += (df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f)) * edge_w(im, Ci, hw, p, p + w) * cy; }
-        if (y > 0)     { const float df = d[p - w] / dn - a; g -= (df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f)) * edge_w(im, Ci, hw, p - w, p) * cy; }
+        if (x + 1 < w) { const float df = v - d[p + 1] / dn; g += (df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f)) * edge_w(im, Ci, hw, p, p + 1) * cx; }
+        if (x > 0)     { const float df = d[p - 1] / dn - v; g -= (df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f)) * edge_w(im, Ci, hw, p - 1, p) * cx; }
+        if (y + 1 < h) { const float df = v - d[p + w] / dn; g += (df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f)) * edge_w(im, Ci, hw, p, p + w) * cy; }
+        if (y > 0)     { const float df = d[p - w] / dn - v; g -= (df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f)) * edge_w(im, Ci, hw, p - w, p) * cy; }
         d_disp[(size_t)b * hw + p] = g;
         dot += g * d[p];
     }
@@ -163,15 +179,53 @@ __global__ __launch_bounds__(256) void smooth_bwd_kernel(const float *__restrict
 }
 
 // pass 2: nd = d / (mean + 1e-7)  =>  d_d[q] = gn[q]/dn - dot/(dn^2 hw)
-__global__ __launch_bounds__(256) void smooth_bwd_finish_kernel(int hw, int B, float *__restrict__ d_disp, const float *__restrict__ ws) {
+__global__ __launch_bounds__(256) void smooth_bwd_finish_kernel(const SmoothArgs a, const float *__restrict__ wsall) {
     __shared__ float red[4];
-    const int b = blockIdx.y;
+    const int b = blockIdx.y, lv = blockIdx.z, B = a.B, hw = a.h[lv] * a.w[lv];
+    const float *ws = wsall + lv * sm_ws_floats(B);
+    float *d_disp = a.d_disp[lv];
     const float dn = sample_mean(ws, B, b, hw, red) + 1e-7f;
     float dot = 0.f;
     for (int k = 0; k < SM_BLK; ++k) dot += ws[B + (size_t)B * SM_BLK * 2 + (size_t)b * SM_BLK + k];
     const float corr = dot / (dn * dn) / (float)hw;
     for (int p = blockIdx.x * 256 + threadIdx.x; p < hw; p += SM_BLK * 256)
         d_disp[(size_t)b * hw + p] = d_disp[(size_t)b * hw + p] / dn - corr;
+}
+
+int smooth_check(const char *fn, const SmoothArgs &a) {
+    MD_REQUIRE(a.S >= 1 && a.S <= SM_MAXS, "%s: %d levels (1..%d)", fn, a.S, SM_MAXS);
+    MD_REQUIRE(a.B > 0 && a.B <= 65535 && a.Ci > 0, "%s: bad dims", fn);
+    for (int s = 0; s < a.S; ++s) {
+        MD_REQUIRE(a.disp[s] && a.img[s], "%s: null tensor at level %d", fn, s);
+        MD_REQUIRE(a.h[s] > 1 && a.w[s] > 1, "%s: level %d is %dx%d (needs h, w > 1)", fn, s, a.h[s], a.w[s]);
+    }
+    return MD_OK;
+}
+
+int smooth_fwd_launch(const SmoothArgs &a, float *loss, void *ws, hipStream_t st) {
+    if (a.normalize) {
+        hipLaunchKernelGGL(smooth_mean_kernel, dim3(SM_BLK, a.B, a.S), dim3(256), 0, st, a, (float *)ws);
+        MD_CHECK_LAUNCH("md_smooth_fwd(mean)");
+    }
+    hipLaunchKernelGGL(smooth_fwd_kernel, dim3(SM_BLK, a.B, a.S), dim3(256), 0, st, a, (float *)ws);
+    MD_CHECK_LAUNCH("md_smooth_fwd");
+    hipLaunchKernelGGL(smooth_finish_kernel, dim3(a.S), dim3(256), 0, st, a, (const float *)ws, loss);
+    MD_CHECK_LAUNCH("md_smooth_fwd(finish)");
+    return MD_OK;
+}
+
+int smooth_bwd_launch(const SmoothArgs &a, void *ws, hipStream_t st) {
+    if (a.normalize) {  // recompute the means: the workspace need not survive between forward and backward
+        hipLaunchKernelGGL(smooth_mean_kernel, dim3(SM_BLK, a.B, a.S), dim3(256), 0, st, a, (float *)ws);
+        MD_CHECK_LAUNCH("md_smooth_bwd(mean)");
+    }
+    hipLaunchKernelGGL(smooth_bwd_kernel, dim3(SM_BLK, a.B, a.S), dim3(256), 0, st, a, (float *)ws);
+    MD_CHECK_LAUNCH("md_smooth_bwd");
+    if (a.normalize) {
+        hipLaunchKernelGGL(smooth_bwd_finish_kernel, dim3(SM_BLK, a.B, a.S), dim3(256), 0, st, a, (const float *)ws);
+        MD_CHECK_LAUNCH("md_smooth_bwd(finish)");
+    }
+    return MD_OK;
 }
 
 }  // namespace
@@ -205,40 +259,56 @@ extern "C" int md_masked_min_bwd(const float *gloss, const float *reproj, const 
 
 extern "C" size_t md_smooth_ws_bytes(int B, int h, int w) {
     (void)h; (void)w;
-    return sizeof(float) * ((size_t)B + (size_t)B * SM_BLK * 4);
+    return sizeof(float) * sm_ws_floats(B);
 }
 
 extern "C" int md_smooth_fwd(const float *disp, const float *img, int B, int Ci, int h, int w, int normalize, float *loss,
                              void *ws, md_stream_t stream) {
     MD_REQUIRE(disp && img && loss && ws, "md_smooth_fwd: null tensor");
-    MD_REQUIRE(B > 0 && B <= 65535 && Ci > 0 && h > 1 && w > 1, "md_smooth_fwd: bad dims");
-    if (normalize) {
-        hipLaunchKernelGGL(smooth_mean_kernel, dim3(SM_BLK, B), dim3(256), 0, (hipStream_t)stream, disp, h * w, B, (float *)ws);
-        MD_CHECK_LAUNCH("md_smooth_fwd(mean)");
-    }
-    hipLaunchKernelGGL(smooth_fwd_kernel, dim3(SM_BLK, B), dim3(256), 0, (hipStream_t)stream, disp, img, Ci, h, w, normalize,
-                       B, (float *)ws);
-    MD_CHECK_LAUNCH("md_smooth_fwd");
-    hipLaunchKernelGGL(smooth_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float *)ws, B, h, w, loss);
-    MD_CHECK_LAUNCH("md_smooth_fwd(finish)");
-    return MD_OK;
+    SmoothArgs a = {};
+    a.disp[0] = disp; a.img[0] = img; a.h[0] = h; a.w[0] = w; a.B = B; a.Ci = Ci; a.normalize = normalize; a.S = 1;
+    int rc = smooth_check("md_smooth_fwd", a);
+    if (rc) return rc;
+    return smooth_fwd_launch(a, loss, ws, (hipStream_t)stream);
 }
 
 extern "C" int md_smooth_bwd(const float *gloss, const float *disp, const float *img, int B, int Ci, int h, int w,
                              int normalize, float *d_disp, void *ws, md_stream_t stream) {
     MD_REQUIRE(gloss && disp && img && d_disp && ws, "md_smooth_bwd: null tensor");
-    MD_REQUIRE(B > 0 && B <= 65535 && Ci > 0 && h > 1 && w > 1, "md_smooth_bwd: bad dims");
-    if (normalize) {  // recompute the means: the workspace need not survive between forward and backward
-        hipLaunchKernelGGL(smooth_mean_kernel, dim3(SM_BLK, B), dim3(256), 0, (hipStream_t)stream, disp, h * w, B, (float *)ws);
-        MD_CHECK_LAUNCH("md_smooth_bwd(mean)");
+    SmoothArgs a = {};
+    a.disp[0] = disp; a.img[0] = img; a.gloss[0] = gloss; a.d_disp[0] = d_disp; a.h[0] = h; a.w[0] = w;
+    a.B = B; a.Ci = Ci; a.normalize = normalize; a.S = 1;
+    int rc = smooth_check("md_smooth_bwd", a);
+    if (rc) return rc;
+    return smooth_bwd_launch(a, ws, (hipStream_t)stream);
+}
+
+extern "C" size_t md_smooth_multi_ws_bytes(int B, int S) { return sizeof(float) * sm_ws_floats(B) * (size_t)(S > 0 ? S : 1); }
+
+extern "C" int md_smooth_multi_fwd(const float *const *disp, const float *const *img, const int *h, const int *w, int S, int B,
+                                   int Ci, int normalize, float *loss, void *ws, md_stream_t stream) {
+    MD_REQUIRE(disp && img && h && w && loss && ws, "md_smooth_multi_fwd: null argument");
+    MD_REQUIRE(S >= 1 && S <= SM_MAXS, "md_smooth_multi_fwd: %d levels (1..%d)", S, SM_MAXS);
+    SmoothArgs a = {};
+    for (int s = 0; s < S; ++s) { a.disp[s] = disp[s]; a.img[s] = img[s]; a.h[s] = h[s]; a.w[s] = w[s]; }
+    a.B = B; a.Ci = Ci; a.normalize = normalize; a.S = S;
+    int rc = smooth_check("md_smooth_multi_fwd", a);
+    if (rc) return rc;
+    return smooth_fwd_launch(a, loss, ws, (hipStream_t)stream);
+}
+
+extern "C" int md_smooth_multi_bwd(const float *const *gloss, const float *const *disp, const float *const *img, const int *h,
+                                   const int *w, int S, int B, int Ci, int normalize, float *const *d_disp, void *ws,
+                                   md_stream_t stream) {
+    MD_REQUIRE(gloss && disp && img && h && w && d_disp && ws, "md_smooth_multi_bwd: null argument");
+    MD_REQUIRE(S >= 1 && S <= SM_MAXS, "md_smooth_multi_bwd: %d levels (1..%d)", S, SM_MAXS);
+    SmoothArgs a = {};
+    for (int s = 0; s < S; ++s) {
+        MD_REQUIRE(d_disp[s], "md_smooth_multi_bwd: null d_disp[%d]", s);
+        a.disp[s] = disp[s]; a.img[s] = img[s]; a.gloss[s] = gloss[s]; a.d_disp[s] = d_disp[s]; a.h[s] = h[s]; a.w[s] = w[s];
     }
-    hipLaunchKernelGGL(smooth_bwd_kernel, dim3(SM_BLK, B), dim3(256), 0, (hipStream_t)stream, gloss, disp, img, Ci, h, w,
-                       normalize, B, d_disp, (float *)ws);
-    MD_CHECK_LAUNCH("md_smooth_bwd");
-    if (normalize) {
-        hipLaunchKernelGGL(smooth_bwd_finish_kernel, dim3(SM_BLK, B), dim3(256), 0, (hipStream_t)stream, h * w, B, d_disp,
-                           (const float *)ws);
-        MD_CHECK_LAUNCH("md_smooth_bwd(finish)");
-    }
-    return MD_OK;
+    a.B = B; a.Ci = Ci; a.normalize = normalize; a.S = S;
+    int rc = smooth_check("md_smooth_multi_bwd", a);
+    if (rc) return rc;
+    return smooth_bwd_launch(a, ws, (hipStream_t)stream);
 }

@@ -102,6 +102,28 @@ __device__ __forceinline__ Proj md_project(const CamMats &m, float r0, float r1,
     return p;
 }
 
+// md_project with the two divisions by the wave-uniform (w-1), (h-1) done through their correctly rounded reciprocals
+// rw = 1/(w-1), rh = 1/(h-1) (Markstein: q = x r, RN(q + (x - q y) r) = the IEEE quotient): same values, 3 instructions each.
+__device__ __forceinline__ Proj md_project_r(const CamMats &m, float r0, float r1, float r2, float d, float wm1, float hm1,
+                                             float rw, float rh) {
+    Proj p;
+    p.X = d * r0;
+    p.Y = d * r1;
+    p.Z = d * r2;
+    float c0 = m.P[0] * p.X + m.P[1] * p.Y + m.P[2] * p.Z + m.P[3];
+    float c1 = m.P[4] * p.X + m.P[5] * p.Y + m.P[6] * p.Z + m.P[7];
+    float c2 = m.P[8] * p.X + m.P[9] * p.Y + m.P[10] * p.Z + m.P[11];
+    p.zz = c2 + 1e-7f;
+    p.u = c0 / p.zz;
+    p.v = c1 / p.zz;
+    const float qx = p.u * rw, qy = p.v * rh;
+    p.gx = (fmaf(fmaf(-qx, wm1, p.u), rw, qx) - 0.5f) * 2.f;
+    p.gy = (fmaf(fmaf(-qy, hm1, p.v), rh, qy) - 0.5f) * 2.f;
+    p.ix = ((p.gx + 1.f) / 2.f) * wm1;
+    p.iy = ((p.gy + 1.f) / 2.f) * hm1;
+    return p;
+}
+
 // v_rcp_f32 (1 ulp) + one Newton step: within 1 ulp of the IEEE quotient at a fifth of its instruction count.
 __device__ __forceinline__ float md_rcp_nr(float x) {
     float r = __builtin_amdgcn_rcpf(x);
@@ -175,6 +197,51 @@ __device__ __forceinline__ Tap md_make_tap(float ix, float iy, int w, int h) {
 }
 
 // ---------------------------------------------------------------- reductions
+// Sum over the 64 lanes with DPP adds only (no ds_bpermute: __shfl_xor goes through the LDS crossbar, and a kernel reducing 24
+// values per wave that way became LDS-bound).  Butterflies inside each row of 16 lanes (quad_perm, row_half_mirror, row_mirror),
+// then row_bcast15 / row_bcast31 carry the row totals up: lane 63 holds the sum, returned to every lane by a readlane.
+__device__ __forceinline__ float md_wave_sum_dpp(float v) {
+#define MD_DPP_ADD(ctrl, rmask)                                                                                          \
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, rmask, 0xF, false))
+    MD_DPP_ADD(0xB1, 0xF);   // quad_perm [1,0,3,2]
+    MD_DPP_ADD(0x4E, 0xF);   // quad_perm [2,3,0,1]
+    MD_DPP_ADD(0x141, 0xF);  // row_half_mirror
+    MD_DPP_ADD(0x140, 0xF);  // row_mirror: every lane of a row holds the row's sum
+    MD_DPP_ADD(0x142, 0xA);  // row_bcast15 into rows 1 and 3
+    MD_DPP_ADD(0x143, 0xC);  // row_bcast31 into rows 2 and 3
+#undef MD_DPP_ADD
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+// Mixed: float butterflies inside each row of 16 lanes (neighbouring pixels: terms of one sign and size, 4 roundings), double
+// from there on (two DPP moves + one v_add_f64 per step) -- for image-wide sums whose terms cancel across regions.
+__device__ __forceinline__ double md_wave_sum_dpp_f16_d(float f) {
+#define MD_DPP_ADDF(ctrl) f += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, f), ctrl, 0xF, 0xF, false))
+    MD_DPP_ADDF(0xB1); MD_DPP_ADDF(0x4E); MD_DPP_ADDF(0x141); MD_DPP_ADDF(0x140);
+#undef MD_DPP_ADDF
+    double v = (double)f;
+#define MD_DPP_ADD(ctrl, rmask)                                                                                          \
+    v += __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(v), ctrl, rmask, 0xF, false),                    \
+                          __builtin_amdgcn_update_dpp(0, __double2loint(v), ctrl, rmask, 0xF, false))
+    MD_DPP_ADD(0x142, 0xA);
+    MD_DPP_ADD(0x143, 0xC);
+#undef MD_DPP_ADD
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
+// all double: for sums whose terms cancel to 1e-3 of their magnitude already inside a wave
+__device__ __forceinline__ double md_wave_sum_dpp(double v) {
+#define MD_DPP_ADD(ctrl, rmask)                                                                                          \
+    v += __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(v), ctrl, rmask, 0xF, false),                    \
+                          __builtin_amdgcn_update_dpp(0, __double2loint(v), ctrl, rmask, 0xF, false))
+    MD_DPP_ADD(0xB1, 0xF);
+    MD_DPP_ADD(0x4E, 0xF);
+    MD_DPP_ADD(0x141, 0xF);
+    MD_DPP_ADD(0x140, 0xF);
+    MD_DPP_ADD(0x142, 0xA);
+    MD_DPP_ADD(0x143, 0xC);
+#undef MD_DPP_ADD
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
+
 __device__ __forceinline__ float md_wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

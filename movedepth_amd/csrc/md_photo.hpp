@@ -27,9 +27,30 @@ __device__ __forceinline__ Clip clip_border(float ix, float iy, int W, int H) {
     return c;
 }
 
+// x / y for a divisor whose correctly rounded reciprocal r = RN(1/y) is at hand (a constant, or wave-uniform and computed once):
+// q = RN(x r), rem = x - q y (exact in an fma), RN(q + rem r) is the correctly rounded quotient (Markstein) -- the value an IEEE
+// division returns, in 3 instructions instead of the ~12 of v_div_scale / v_rcp / 5 fma / v_div_fmas / v_div_fixup.  The window
+// means (x / 9, five per SSIM value) were 40 % of the fused forward's VALU instructions as IEEE divisions.
+__device__ __forceinline__ float div_by(float x, float y, float r) {
+    const float q = x * r;
+    return fmaf(fmaf(-q, y, x), r, q);
+}
+__device__ __forceinline__ float div9(float x) { return div_by(x, 9.f, 1.f / 9.f); }
+
 // F.interpolate(bilinear, align_corners=False) source taps of output index o (trainer.py:512)
 __device__ __forceinline__ void interp_idx(int o, int in, int out, int &i0, int &i1, float &l1) {
     const float scale = (float)in / (float)out;
+    float s = scale * ((float)o + 0.5f) - 0.5f;
+    if (s < 0.f) s = 0.f;
+    int a = (int)s;
+    if (a > in - 1) a = in - 1;
+    i0 = a;
+    i1 = a < in - 1 ? a + 1 : a;
+    l1 = s - (float)a;
+}
+
+// the same with scale = (float)in / (float)out hoisted by the caller (wave-uniform: one IEEE division per kernel, not two per pixel)
+__device__ __forceinline__ void interp_idx_s(int o, int in, float scale, int &i0, int &i1, float &l1) {
     float s = scale * ((float)o + 0.5f) - 0.5f;
     if (s < 0.f) s = 0.f;
     int a = (int)s;
@@ -44,8 +65,8 @@ __device__ __forceinline__ float disp_up_sd(const float *__restrict__ s, int h, 
                                             float min_disp, float max_disp) {
     int x0, x1, y0, y1;
     float lx, ly;
-    interp_idx(x, w, W, x0, x1, lx);
-    interp_idx(y, h, H, y0, y1, ly);
+    interp_idx_s(x, w, (float)w / (float)W, x0, x1, lx);   // the quotients are wave-uniform: hoisted out of any loop
+    interp_idx_s(y, h, (float)h / (float)H, y0, y1, ly);
     const float v = (1.f - ly) * ((1.f - lx) * s[y0 * w + x0] + lx * s[y0 * w + x1]) +
                     ly * ((1.f - lx) * s[y1 * w + x0] + lx * s[y1 * w + x1]);
     return min_disp + (max_disp - min_disp) * v;

@@ -40,25 +40,48 @@ struct Sample3 {
     float v[3];
 };
 
-// grid_sample(border, align_corners=True) of a 3-channel image at the clipped position (the forward of warp.hip)
+// grid_sample(border, align_corners=True) of a 3-channel image at the clipped position (the forward of warp.hip).
+// All twelve loads are unconditional, from clamped addresses, and selected to zero afterwards: a load under a (divergent)
+// branch sits in its own basic block behind an s_waitcnt, which made the twelve taps twelve SERIAL memory round trips
+// (the 4-scale forward spent 72 % of its wave cycles parked; so does warp_fwd_kernel, 13 us for 0.7 M pixels).
 __device__ __forceinline__ Sample3 sample_border(const float *__restrict__ img, size_t HW, int W, int H, const Clip &c) {
     const Tap t = md_make_tap(c.ix, c.iy, W, H);
-    const int x1 = t.x0 + 1, y1 = t.y0 + 1;
-    const bool vx1 = x1 < W, vy1 = y1 < H;  // x0, y0 are in range after clipping
+    const bool vx1 = t.x0 + 1 < W, vy1 = t.y0 + 1 < H;  // x0, y0 are in range after clipping
+    const int x1 = vx1 ? t.x0 + 1 : t.x0, y1 = vy1 ? t.y0 + 1 : t.y0;
     const float wx0 = 1.f - t.wx1, wy0 = 1.f - t.wy1;
-    Sample3 o;
+    const int o00 = t.y0 * W + t.x0, o01 = t.y0 * W + x1, o10 = y1 * W + t.x0, o11 = y1 * W + x1;
+    float v[3][4];
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
         const float *im = img + ch * HW;
-        float a = im[t.y0 * W + t.x0] * (wy0 * wx0);
-        if (vx1) a += im[t.y0 * W + x1] * (wy0 * t.wx1);
-        if (vy1) a += im[y1 * W + t.x0] * (t.wy1 * wx0);
-        if (vx1 && vy1) a += im[y1 * W + x1] * (t.wy1 * t.wx1);
+        v[ch][0] = im[o00]; v[ch][1] = im[o01]; v[ch][2] = im[o10]; v[ch][3] = im[o11];
+    }
+    Sample3 o;
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+        float a = v[ch][0] * (wy0 * wx0);   // explicit fma chain, as warp_fwd_kernel: bit-equal results
+        a = fmaf(vx1 ? v[ch][1] : 0.f, wy0 * t.wx1, a);
+        a = fmaf(vy1 ? v[ch][2] : 0.f, t.wy1 * wx0, a);
+        a = fmaf((vx1 && vy1) ? v[ch][3] : 0.f, t.wy1 * t.wx1, a);
         o.v[ch] = a;
     }
     return o;
 }
 
+
+// Work item of this workgroup.  Workgroups are dealt round-robin to the 8 XCDs (block b -> XCD b % 8: observed, relied on for
+// speed only), each with its own 4 MB L2; the images of one call are 26 MB at config 2.  Every XCD therefore gets a
+// contiguous eighth of the (sample, tile) items -- 3.3 MB of images: L2-resident -- and runs the S scales of an item back to
+// back, so a tile's target / source lines miss to the Infinity Cache once instead of once per scale (PMC before: 314 MB
+// fetched by the 4-scale forward for 30 MB of inputs, waves parked 72 % of their cycles on those misses).
+__device__ __forceinline__ bool photo_item(int nitems, int S, int &item, int &s) {
+    const int bid = blockIdx.x, xcd = bid & 7, j = bid >> 3;
+    const int per = (nitems + 7) >> 3;
+    item = xcd * per + j / S;
+    s = j % S;
+    return j / S < per && item < nitems;
+}
+__host__ inline unsigned photo_grid(int nitems, int S) { return 8u * (unsigned)((nitems + 7) / 8) * (unsigned)S; }
 
 // P = (K T)[:3] of every frame and inv_K[:3,:3], computed once per workgroup (12 F + 9 threads), read back by everyone
 template <int F>
@@ -94,17 +117,22 @@ __global__ __launch_bounds__(256) void photo_fwd_kernel(const md_photo_desc a, f
     __shared__ float red[4][2];
     __shared__ float camS[MAXF * 12 + 9];
     const int tid = threadIdx.x;
-    const int s = blockIdx.z / a.B, b = blockIdx.z % a.B;
-    const int x0 = blockIdx.x * FT_W, y0 = blockIdx.y * FT_H;
+    const int H = a.H, W = a.W;
+    const int tiles_x = (W + FT_W - 1) / FT_W, tiles = tiles_x * ((H + FT_H - 1) / FT_H);
+    int item, s;
+    if (!photo_item(a.B * tiles, IDENT ? 1 : a.S, item, s)) return;
+    const int b = item / tiles, tile = item % tiles;
+    const int x0 = (tile % tiles_x) * FT_W, y0 = (tile / tiles_x) * FT_H;
     CamMats cam[F];
     if (!IDENT) load_cams<F>(a, b, camS, cam);
-    const int H = a.H, W = a.W;
     const size_t HW = (size_t)H * W;
     const float *tgt = a.target + (size_t)b * 3 * HW;
     const float min_disp = 1.f / a.max_depth, max_disp = 1.f / a.min_depth;
+    const float wm1 = (float)(W - 1), hm1 = (float)(H - 1), rw = 1.f / wm1, rh = 1.f / hm1;
 
-    // ---- phase 1: every halo position -> target + F predictions in LDS
-#pragma unroll 1
+    // ---- phase 1: every halo position -> target + F predictions in LDS.  Unrolled: the loads of a thread's (up to) three
+    // positions are independent and should all be in flight together -- the kernel is bound by memory latency, not bandwidth
+#pragma unroll
     for (int i = tid; i < FP_N; i += 256) {
         const int cy = i / FP_W, cx = i % FP_W;
         const int gy = y0 - 1 + cy, gx = x0 - 1 + cx;
@@ -124,11 +152,11 @@ __global__ __launch_bounds__(256) void photo_fwd_kernel(const md_photo_desc a, f
             if (a.is_disp) depth = 1.f / disp_up_sd(a.dz[s] + (size_t)b * a.dh[s] * a.dw[s], a.dh[s], a.dw[s], H, W, py, px, min_disp, max_disp);
             else depth = a.dz[s][(size_t)b * HW + p];
             if (own && a.depth_out[s]) a.depth_out[s][(size_t)b * HW + p] = depth;
+            float r0, r1, r2;
+            md_ray(cam[0], (float)px, (float)py, r0, r1, r2);   // inv_K is the same for every frame
 #pragma unroll
             for (int f = 0; f < F; ++f) {
-                float r0, r1, r2;
-                md_ray(cam[f], (float)px, (float)py, r0, r1, r2);
-                const Proj pr = md_project(cam[f], r0, r1, r2, depth, W, H);
+                const Proj pr = md_project_r(cam[f], r0, r1, r2, depth, wm1, hm1, rw, rh);
                 const Clip c = clip_border(pr.ix, pr.iy, W, H);
                 const Sample3 o = sample_border(a.src[f] + (size_t)b * 3 * HW, HW, W, H, c);
                 wp[f * FP_N + i] = make_float4(o.v[0], o.v[1], o.v[2], 0.f);
@@ -137,7 +165,7 @@ __global__ __launch_bounds__(256) void photo_fwd_kernel(const md_photo_desc a, f
                         float *w_ = a.warped[s][f] + (size_t)b * 3 * HW + p;
                         w_[0] = o.v[0]; w_[HW] = o.v[1]; w_[2 * HW] = o.v[2];
                     }
-                    if (a.pix[s][f]) { float *q = a.pix[s][f] + ((size_t)b * HW + p) * 2; q[0] = pr.gx; q[1] = pr.gy; }
+                    if (a.pix[s][f]) *reinterpret_cast<float2 *>(a.pix[s][f] + ((size_t)b * HW + p) * 2) = make_float2(pr.gx, pr.gy);
                     if (s == 0 && a.oob[f])
                         a.oob[f][(size_t)b * HW + p] = (pr.gx < -1.f || pr.gx > 1.f || pr.gy < -1.f || pr.gy > 1.f) ? 1 : 0;
                 }
@@ -209,8 +237,8 @@ __global__ __launch_bounds__(256) void photo_fwd_kernel(const md_photo_desc a, f
                     l1 += fabsf(yc[k][c] - xc[k][c]);
                     if (use_ssim) {
                         Moments m;
-                        m.mux = mux[k][c] / 9.f; m.ex2 = ex2[k][c] / 9.f; m.exy = exy[k][c] / 9.f;
-                        m.muy = muy[k][c] / 9.f; m.ey2 = ey2[k][c] / 9.f;
+                        m.mux = div9(mux[k][c]); m.ex2 = div9(ex2[k][c]); m.exy = div9(exy[k][c]);
+                        m.muy = div9(muy[k][c]); m.ey2 = div9(ey2[k][c]);
                         const float sv = ssim_from(m, nullptr, nullptr);
                         ss += fminf(fmaxf(sv, 0.f), 1.f);  // torch.clamp(., 0, 1)
                     }
@@ -254,7 +282,7 @@ __global__ __launch_bounds__(256) void photo_fwd_kernel(const md_photo_desc a, f
         if ((tid & 63) == 0) { red[tid >> 6][0] = num; red[tid >> 6][1] = den; }
         __syncthreads();
         if (tid == 0) {
-            const size_t blk = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+            const size_t blk = ((size_t)s * a.B + b) * tiles + tile;
             ws[blk * 2] = red[0][0] + red[1][0] + red[2][0] + red[3][0];
             ws[blk * 2 + 1] = red[0][1] + red[1][1] + red[2][1] + red[3][1];
         }
@@ -292,19 +320,22 @@ __global__ __launch_bounds__(256) void photo_bwd_kernel(const md_photo_desc a, f
     __shared__ double red[4][12];
     __shared__ float camS[MAXF * 12 + 9];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int s = blockIdx.z / a.B, b = blockIdx.z % a.B;
-    const int x0 = blockIdx.x * BT_W, y0 = blockIdx.y * BT_H;
+    const int H = a.H, W = a.W;
+    const int tiles_x = (W + BT_W - 1) / BT_W, nblk = tiles_x * ((H + BT_H - 1) / BT_H);
+    int item, s;
+    if (!photo_item(a.B * nblk, a.S, item, s)) return;
+    const int b = item / nblk, blk = item % nblk;
+    const int x0 = (blk % tiles_x) * BT_W, y0 = (blk / tiles_x) * BT_H;
     CamMats cam[F];
     load_cams<F>(a, b, camS, cam);
-    const int H = a.H, W = a.W;
     const size_t HW = (size_t)H * W;
     const float min_disp = 1.f / a.max_depth, max_disp = 1.f / a.min_depth;
+    const float wm1 = (float)(W - 1), hm1 = (float)(H - 1), rw = 1.f / wm1, rh = 1.f / hm1;
     const bool use_ssim = !a.no_ssim && a.ssim_w != 0.f;
     const float wl1 = a.no_ssim ? 1.f : (1.f - a.ssim_w);
     // d loss_s / d (min * mask)[p] = gloss_s / (sum(mask) + 1e-7)
     const float gscale = a.gloss[s] ? a.gloss[s][0] / (a.loss[s * 2 + 1] + 1e-7f) : 0.f;
     const unsigned char *selb = a.sel[s] + (size_t)b * HW;
-    const int nblk = gridDim.x * gridDim.y, blk = blockIdx.y * gridDim.x + blockIdx.x;
 
     {
         const float *tgt = a.target + (size_t)b * 3 * HW;
@@ -354,19 +385,31 @@ __global__ __launch_bounds__(256) void photo_bwd_kernel(const md_photo_desc a, f
                 if (py >= 0 && py < H && px >= 0 && px < W && selb[(size_t)py * W + px] == (unsigned char)(0x80 | f)) {
                     const float gs = gscale * (maskb ? maskb[(size_t)py * W + px] : 1.f) * a.ssim_w / 3.f;
                     float cA[3], cB[3], cC[3];
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) {
+                    {
+                        // each tap's float4 is read from LDS once for its three channels (read per channel, the kernel issued 400
+                        // DS instructions per wave and was LDS-bound: SQ_LDS_IDX_ACTIVE 60 % of its duration); sums in the
+                        // reference's order, no contraction (see the forward)
 #pragma clang fp contract(off)
-                        Moments m = {0.f, 0.f, 0.f, 0.f, 0.f};
+                        Moments m[3];
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) m[c] = Moments{0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                         for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
                             for (int dx = 0; dx < 3; ++dx) {
-                                const float xv = f4c(wf[(cy + dy) * B2_W + cx + dx], c), yv = f4c(tg[(cy + dy) * B2_W + cx + dx], c);
-                                m.mux += xv; m.muy += yv; m.ex2 += xv * xv; m.ey2 += yv * yv; m.exy += xv * yv;
+                                const float4 x4 = wf[(cy + dy) * B2_W + cx + dx], y4 = tg[(cy + dy) * B2_W + cx + dx];
+#pragma unroll
+                                for (int c = 0; c < 3; ++c) {
+                                    const float xv = f4c(x4, c), yv = f4c(y4, c);
+                                    m[c].mux += xv; m[c].muy += yv; m[c].ex2 += xv * xv; m[c].ey2 += yv * yv; m[c].exy += xv * yv;
+                                }
                             }
-                        m.mux /= 9.f; m.muy /= 9.f; m.ex2 /= 9.f; m.ey2 /= 9.f; m.exy /= 9.f;
-                        ssim_coeffs(m, gs, cA[c], cB[c], cC[c]);
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            m[c].mux = div9(m[c].mux); m[c].muy = div9(m[c].muy); m[c].ex2 = div9(m[c].ex2);
+                            m[c].ey2 = div9(m[c].ey2); m[c].exy = div9(m[c].exy);
+                            ssim_coeffs(m[c], gs, cA[c], cB[c], cC[c]);
+                        }
                     }
                     A = make_float4(cA[0], cA[1], cA[2], 0.f);
                     Bc = make_float4(cB[0], cB[1], cB[2], 0.f);
@@ -376,9 +419,9 @@ __global__ __launch_bounds__(256) void photo_bwd_kernel(const md_photo_desc a, f
             }
             __syncthreads();
         }
-        double dP[12];
+        float dP[12];
 #pragma unroll
-        for (int k = 0; k < 12; ++k) dP[k] = 0.0;
+        for (int k = 0; k < 12; ++k) dP[k] = 0.f;
         if (qvalid) {
             // ---- d loss / d pred_f[q][c]
             float gA[3] = {0.f, 0.f, 0.f}, gB[3] = {0.f, 0.f, 0.f}, gC[3] = {0.f, 0.f, 0.f};
@@ -418,20 +461,26 @@ __global__ __launch_bounds__(256) void photo_bwd_kernel(const md_photo_desc a, f
             }
             // ---- the warp's backward at q (warp.hip): gradients to the depth and to P = (K T)[:3]
             if (any) {
-                const Proj pr = md_project(cam[f], r0, r1, r2, depth, W, H);
+                const Proj pr = md_project_r(cam[f], r0, r1, r2, depth, wm1, hm1, rw, rh);
                 const Clip c = clip_border(pr.ix, pr.iy, W, H);
                 const Tap t = md_make_tap(c.ix, c.iy, W, H);
-                const int x1 = t.x0 + 1, y1 = t.y0 + 1;
-                const bool vx1 = x1 < W, vy1 = y1 < H;
+                const bool vx1 = t.x0 + 1 < W, vy1 = t.y0 + 1 < H;
+                const int x1 = vx1 ? t.x0 + 1 : t.x0, y1 = vy1 ? t.y0 + 1 : t.y0;   // unconditional loads, see sample_border
                 const float wx0 = 1.f - t.wx1, wy0 = 1.f - t.wy1;
                 float gix = 0.f, giy = 0.f;
+                float tv[3][4];
 #pragma unroll
                 for (int ch = 0; ch < 3; ++ch) {
                     const float *im = a.src[f] + ((size_t)b * 3 + ch) * HW;
-                    const float nw = im[t.y0 * W + t.x0];
-                    const float ne = vx1 ? im[t.y0 * W + x1] : 0.f;
-                    const float sw = vy1 ? im[y1 * W + t.x0] : 0.f;
-                    const float se = (vx1 && vy1) ? im[y1 * W + x1] : 0.f;
+                    tv[ch][0] = im[t.y0 * W + t.x0]; tv[ch][1] = im[t.y0 * W + x1];
+                    tv[ch][2] = im[y1 * W + t.x0]; tv[ch][3] = im[y1 * W + x1];
+                }
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) {
+                    const float nw = tv[ch][0];
+                    const float ne = vx1 ? tv[ch][1] : 0.f;
+                    const float sw = vy1 ? tv[ch][2] : 0.f;
+                    const float se = (vx1 && vy1) ? tv[ch][3] : 0.f;
                     gix += dpred[ch] * ((ne - nw) * wy0 + (se - sw) * t.wy1);
                     giy += dpred[ch] * ((sw - nw) * wx0 + (se - ne) * t.wx1);
                 }
@@ -447,17 +496,17 @@ __global__ __launch_bounds__(256) void photo_bwd_kernel(const md_photo_desc a, f
 #pragma unroll
                     for (int i = 0; i < 3; ++i)
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) dP[i * 4 + j] = (double)(dc[i] * Xh[j]);
+                        for (int j = 0; j < 4; ++j) dP[i * 4 + j] = dc[i] * Xh[j];
                 }
             }
         }
         if (a.d_T[f]) {
-            // per-workgroup partial sums of dL/dP, in double: the terms cancel to ~1 % of their absolute sum
+            // partial sums of dL/dP: float inside each row of 16 lanes (neighbouring pixels), double across rows, waves, workgroups
+            // and scales -- the terms cancel across image regions.  DPP moves, no ds_bpermute: as __shfl_xor on doubles this was
+            // 288 LDS-crossbar instructions per wave and the kernel was LDS-bound (260 -> 171 us for the 4-scale backward).
 #pragma unroll
             for (int k = 0; k < 12; ++k) {
-                double v = dP[k];
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+                const double v = md_wave_sum_dpp_f16_d(dP[k]);
                 if (lane == 0) red[wave][k] = v;
             }
             __syncthreads();
@@ -538,16 +587,21 @@ __global__ __launch_bounds__(256) void up_adjoint_kernel(const md_photo_desc a, 
             oy_lo = max(0, (int)floorf(((float)iy - 1.f) * fy) - 1); oy_hi = min(H - 1, (int)ceilf(((float)iy + 2.f) * fy) + 1);
             ox_lo = max(0, (int)floorf(((float)ix - 1.f) * fx) - 1); ox_hi = min(W - 1, (int)ceilf(((float)ix + 2.f) * fx) + 1);
         }
-        const int fw = ox_hi - ox_lo + 1, n = fw * (oy_hi - oy_lo + 1);
+        const int fw = ox_hi - ox_lo + 1;
         const float *g = gup + ((size_t)s * a.B + b) * H * W;
+        const float sy = (float)h / (float)H, sx = (float)w / (float)W;
+        // same size: F.interpolate is the identity (source index = o exactly, weight 1) -- the window loop cost scale 0 nine
+        // iterations per pixel for one non-zero term
+        const int n = (h == H && w == W) ? 0 : fw * (oy_hi - oy_lo + 1);
+        if (n == 0) acc = g[(size_t)iy * W + ix];
         for (int k = sub; k < n; k += lpp) {
             const int oy = oy_lo + k / fw, ox = ox_lo + k % fw;
             int y0, y1; float ly;
-            interp_idx(oy, h, H, y0, y1, ly);
+            interp_idx_s(oy, h, sy, y0, y1, ly);
             const float wy = (y0 == iy ? 1.f - ly : 0.f) + (y1 == iy ? ly : 0.f);
             if (wy == 0.f) continue;
             int x0, x1; float lx;
-            interp_idx(ox, w, W, x0, x1, lx);
+            interp_idx_s(ox, w, sx, x0, x1, lx);
             const float wx = (x0 == ix ? 1.f - lx : 0.f) + (x1 == ix ? lx : 0.f);
             if (wx == 0.f) continue;
             acc += g[(size_t)oy * W + ox] * wy * wx;
@@ -561,8 +615,7 @@ int check_desc(const char *fn, const md_photo_desc *d) {
     MD_REQUIRE(d, "%s: null descriptor", fn);
     MD_REQUIRE(d->B > 0 && d->B <= 4096 && d->H >= 3 && d->W >= 3, "%s: bad dims B=%d H=%d W=%d (H, W >= 3)", fn, d->B, d->H, d->W);
     MD_REQUIRE(d->F >= 1 && d->F <= MAXF && d->S >= 1 && d->S <= MAXS, "%s: F=%d (1..%d), S=%d (1..%d)", fn, d->F, MAXF, d->S, MAXS);
-    MD_REQUIRE((long long)d->B * d->S <= 65535, "%s: B*S too large", fn);
-    MD_REQUIRE(d->target, "%s: null target", fn);
+        MD_REQUIRE(d->target, "%s: null target", fn);
     for (int f = 0; f < d->F; ++f) MD_REQUIRE(d->src[f], "%s: null src[%d]", fn, f);
     if (!d->identity) {
         MD_REQUIRE(d->K && d->invK, "%s: null K / invK", fn);
@@ -578,6 +631,8 @@ int check_desc(const char *fn, const md_photo_desc *d) {
 
 }  // namespace
 
+extern "C" size_t md_photo_desc_bytes(void) { return sizeof(md_photo_desc); }
+
 extern "C" size_t md_photo_fwd_ws_bytes(int B, int S, int H, int W) {
     return sizeof(float) * 2 * (size_t)B * S * md_cdiv(W, FT_W) * md_cdiv(H, FT_H);
 }
@@ -591,7 +646,8 @@ extern "C" int md_photo_fwd(const md_photo_desc *d, void *ws, md_stream_t stream
     } else {
         MD_REQUIRE(d->mn[0], "md_photo_fwd: identity mode writes mn[0]");
     }
-    dim3 grid(md_cdiv(d->W, FT_W), md_cdiv(d->H, FT_H), d->B * S);
+    const int tiles = md_cdiv(d->W, FT_W) * md_cdiv(d->H, FT_H);
+    dim3 grid(photo_grid(d->B * tiles, S));
     const size_t lds = sizeof(float4) * (size_t)(1 + F) * FP_N;
     hipStream_t st = (hipStream_t)stream;
 #define MD_PH_FWD(F_)                                                                                                       \
@@ -603,7 +659,7 @@ extern "C" int md_photo_fwd(const md_photo_desc *d, void *ws, md_stream_t stream
 #undef MD_PH_FWD
     MD_CHECK_LAUNCH("md_photo_fwd");
     if (!d->identity) {
-        hipLaunchKernelGGL(photo_fwd_finish_kernel, dim3(S), dim3(256), 0, st, (const float *)ws, (int)(grid.x * grid.y * d->B), d->loss);
+        hipLaunchKernelGGL(photo_fwd_finish_kernel, dim3(S), dim3(256), 0, st, (const float *)ws, tiles * d->B, d->loss);
         MD_CHECK_LAUNCH("md_photo_fwd(finish)");
     }
     return MD_OK;
@@ -624,8 +680,8 @@ extern "C" int md_photo_bwd(const md_photo_desc *d, void *ws, md_stream_t stream
         for (int f = 0; f < d->F; ++f) MD_REQUIRE(d->warped[s][f], "md_photo_bwd: the forward's warped[%d][%d] is required", s, f);
     }
     const int F = d->F;
-    dim3 grid(md_cdiv(d->W, BT_W), md_cdiv(d->H, BT_H), d->B * d->S);
-    const int nblk = grid.x * grid.y;
+    const int nblk = md_cdiv(d->W, BT_W) * md_cdiv(d->H, BT_H);
+    dim3 grid(photo_grid(d->B * nblk, d->S));
     float *wsP = (float *)ws;
     float *gup = wsP + (size_t)12 * d->S * F * d->B * nblk;
     const size_t lds = sizeof(float4) * ((size_t)(1 + F) * B2_N + 3 * B1_N);

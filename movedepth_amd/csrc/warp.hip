@@ -36,9 +36,9 @@ __global__ __launch_bounds__(256) void warp_fwd_kernel(const float *__restrict__
     for (int ch = 0; ch < Ci; ++ch) {
         const float *im = img + ((size_t)b * Ci + ch) * HW;
         float o = im[t.y0 * W + t.x0] * (wy0 * wx0);
-        if (vx1) o += im[t.y0 * W + x1] * (wy0 * t.wx1);
-        if (vy1) o += im[y1 * W + t.x0] * (t.wy1 * wx0);
-        if (vx1 && vy1) o += im[y1 * W + x1] * (t.wy1 * t.wx1);
+        if (vx1) o = fmaf(im[t.y0 * W + x1], wy0 * t.wx1, o);
+        if (vy1) o = fmaf(im[y1 * W + t.x0], t.wy1 * wx0, o);
+        if (vx1 && vy1) o = fmaf(im[y1 * W + x1], t.wy1 * t.wx1, o);
         out[((size_t)b * Ci + ch) * HW + p] = o;
     }
 }

@@ -578,6 +578,54 @@ def smooth_loss(disp, img, normalize=True):
     return _Smooth.apply(disp, img, bool(normalize))
 
 
+class _SmoothMulti(torch.autograd.Function):
+    """get_smooth_loss of every pyramid level in one launch per pass (md_smooth_multi_*)."""
+
+    @staticmethod
+    def forward(ctx, normalize, S, *tensors):
+        disps = [_prep(t, "disp") for t in tensors[:S]]
+        imgs = [_prep(t, "img") for t in tensors[S:]]
+        B, Ci = imgs[0].shape[:2]
+        hs = (ctypes.c_int * S)(*[im.shape[2] for im in imgs])
+        ws_ = (ctypes.c_int * S)(*[im.shape[3] for im in imgs])
+        loss = torch.empty(S, device=disps[0].device, dtype=torch.float32)
+        ws = _ws(_lib.load().md_smooth_multi_ws_bytes(B, S), disps[0].device)
+        dp = (ctypes.c_void_p * S)(*[d.data_ptr() for d in disps])
+        ip = (ctypes.c_void_p * S)(*[i.data_ptr() for i in imgs])
+        _lib.call("md_smooth_multi_fwd", dp, ip, hs, ws_, S, B, Ci, int(normalize), _p(loss), _p(ws), _stream())
+        ctx.save_for_backward(*disps, *imgs)
+        ctx.meta = (int(normalize), S)
+        ctx.set_materialize_grads(False)
+        return tuple(loss[s] for s in range(S))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        normalize, S = ctx.meta
+        saved = ctx.saved_tensors
+        disps, imgs = saved[:S], saved[S:]
+        B, Ci = imgs[0].shape[:2]
+        gl = [None if g is None else g.reshape(1).contiguous().float() for g in grads]
+        dd = [torch.empty_like(d) for d in disps]
+        hs = (ctypes.c_int * S)(*[im.shape[2] for im in imgs])
+        ws_ = (ctypes.c_int * S)(*[im.shape[3] for im in imgs])
+        ws = _ws(_lib.load().md_smooth_multi_ws_bytes(B, S), disps[0].device)
+        gp = (ctypes.c_void_p * S)(*[_ptr(g) for g in gl])
+        dp = (ctypes.c_void_p * S)(*[d.data_ptr() for d in disps])
+        ip = (ctypes.c_void_p * S)(*[i.data_ptr() for i in imgs])
+        op = (ctypes.c_void_p * S)(*[d.data_ptr() for d in dd])
+        _lib.call("md_smooth_multi_bwd", gp, dp, ip, hs, ws_, S, B, Ci, normalize, op, _p(ws), _stream())
+        return (None, None) + tuple(dd) + (None,) * S
+
+
+def smooth_losses(disps, imgs, normalize=True):
+    """smooth_loss(disps[s], imgs[s]) for every pyramid level s (reference trainer.py:712-714 in its scale loop), one launch
+    per pass for all of them.  Returns a list of scalars."""
+    S = len(disps)
+    if not (1 <= S <= _lib.PHOTO_MAX_SCALES) or len(imgs) != S:
+        raise _lib.MovedepthHipError("smooth_losses: %d disparity levels / %d images (1..4, equal)" % (S, len(imgs)))
+    return list(_SmoothMulti.apply(bool(normalize), S, *disps, *imgs))
+
+
 # --------------------------------------------------------------------------- post-volume regression
 class _SoftmaxEntropyLocalmax(torch.autograd.Function):
     @staticmethod

@@ -540,6 +540,9 @@ class Trainer:
 
         ident = None if (opt.disable_automasking or fused is not None) else self._identity_losses(inputs)  # same values at every scale
         total_loss = 0
+        smooth = None
+        if opt.fused_photometric:   # every level's smoothness term in one launch per pass
+            smooth = ops.smooth_losses([outputs[("disp", sc)] for sc in opt.scales], [inputs[("color", 0, sc)] for sc in opt.scales])
         for si, scale in enumerate(opt.scales):
             if fused is not None:   # formed by generate_images_pred's launch
                 loss, min_reproj = fused["loss"][si], fused["min"][si]
@@ -552,7 +555,8 @@ class Trainer:
                     loss, min_reproj, _ = ops.masked_min_loss(reprojection_losses)
             if scale == 0:
                 outputs["mono_reproj_loss"] = min_reproj
-            smooth_loss = ops.smooth_loss(outputs[("disp", scale)], inputs[("color", 0, scale)], normalize=True)
+            smooth_loss = smooth[si] if smooth is not None else \
+                ops.smooth_loss(outputs[("disp", scale)], inputs[("color", 0, scale)], normalize=True)
             losses["mono_smooth_loss/{}".format(scale)] = smooth_loss
             loss = loss + opt.disparity_smoothness * smooth_loss / (2 ** scale)
             total_loss = total_loss + loss

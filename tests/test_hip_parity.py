@@ -469,6 +469,28 @@ def test_smooth_vs_oracle_and_golden(ops, oracle_lib, normalize):
     assert_close(host(dd.grad), oracle_lib.smooth_loss_bwd(2.0, disp, img, normalize))
 
 
+def test_smooth_all_levels_in_one_launch_vs_oracle(ops, oracle_lib):
+    """md_smooth_multi_*: the four pyramid levels of one compute_losses call (trainer.py:712-714) in one launch per pass,
+    each level against the oracle's get_smooth_loss (layers.py:630-643) and its gradient; one level left without an upstream
+    gradient (its d_disp must be zero)."""
+    rng = np.random.default_rng(19)
+    B, H, W = 2, 96, 160
+    disps = [(0.01 + rng.random((B, 1, H >> s, W >> s))).astype(np.float32) for s in range(4)]
+    imgs = [smooth_field(rng, (B, 3, H >> s, W >> s), 4) for s in range(4)]
+    td = [dev(d, True) for d in disps]
+    losses = ops.smooth_losses(td, [dev(i) for i in imgs])
+    gl = [1.0, 0.5, None, 2.0]
+    for s in range(4):
+        e = oracle_lib.smooth_loss(disps[s], imgs[s], True)
+        assert abs(float(losses[s].detach()) - e) < 2e-5 * e, (s, float(losses[s]), e)
+    sum(g * l for g, l in zip(gl, losses) if g is not None).backward()
+    for s in range(4):
+        if gl[s] is None:
+            assert float(td[s].grad.abs().max()) == 0.0
+        else:
+            assert_close(host(td[s].grad), oracle_lib.smooth_loss_bwd(gl[s], disps[s], imgs[s], True), what="d_disp[%d]" % s)
+
+
 # ------------------------------------------------------------------ post-volume
 def test_postvol_golden(ops):
     g = load_golden("postvol")
