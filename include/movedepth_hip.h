@@ -231,11 +231,13 @@ int md_softmax_entropy_localmax_bwd(const float *g_depth, const float *g_entropy
                                     float *d_logits, md_stream_t stream);
 
 /* Convex upsampling (layers.py:200-214): depth [B,h,w], mask [B,9*s*s,h,w] (s = 2**scale) -> out [B,s*h,s*w]
- * (softmax over the 9 taps of a zero-padded 3x3 unfold).  Backward: d_depth [B,h,w], d_mask like mask. */
+ * (softmax over the 9 taps of a zero-padded 3x3 unfold).  Backward: d_depth [B,h,w], d_mask like mask;
+ * ws: md_convex_upsample_bwd_ws_bytes(B,h,w) bytes (per-cell sums of the terms of the depth gradient). */
 int md_convex_upsample_fwd(const float *depth, const float *mask, int B, int h, int w, int scale, float *out,
                            md_stream_t stream);
+size_t md_convex_upsample_bwd_ws_bytes(int B, int h, int w);
 int md_convex_upsample_bwd(const float *gout, const float *depth, const float *mask, int B, int h, int w, int scale,
-                           float *d_depth, float *d_mask, md_stream_t stream);
+                           float *d_depth, float *d_mask, void *ws, md_stream_t stream);
 
 /* ---- reg3d's last layer, the producer of the logits above (the 3-D conv hand-off) ------------
  * `prob = nn.Conv3d(base_channels, 1, 3, stride=1, padding=1, bias=False)` (networks/resnet_encoder.py:254,

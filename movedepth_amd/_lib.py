@@ -55,7 +55,8 @@ SIGNATURES = {
     "md_softmax_entropy_localmax_fwd": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "md_softmax_entropy_localmax_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "md_convex_upsample_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
-    "md_convex_upsample_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "md_convex_upsample_bwd_ws_bytes": (_sz, [_i, _i, _i]),
+    "md_convex_upsample_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "md_conv3d_c1_fwd": (_i, [_vp, _vp, _ll, _ll, _vp, _i, _i, _i, _i, _i, _vp]),
     "md_conv3d_c1_bwd_data": (_i, [_vp, _vp, _ll, _ll, _vp, _i, _i, _i, _i, _i, _vp]),
     "md_conv3d_c1_bwd_weight_ws_bytes": (_sz, [_i, _i, _i, _i, _i]),

@@ -317,7 +317,7 @@ __global__ __launch_bounds__(256) void photo_bwd_kernel(const md_photo_desc a, f
     float4 *tg = lds;                         // target, halo 2
     float4 *wp = lds + B2_N;                  // wp[f * B2_N + i]: warped frame f, halo 2
     float4 *cf = lds + (1 + F) * B2_N;        // cf[k * B1_N + i], k = 0..2: coefficient maps A, B, C of the current frame
-    __shared__ double red[4][12];
+    __shared__ float redf[16 * 12];
     __shared__ float camS[MAXF * 12 + 9];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int H = a.H, W = a.W;
@@ -326,8 +326,6 @@ __global__ __launch_bounds__(256) void photo_bwd_kernel(const md_photo_desc a, f
     if (!photo_item(a.B * nblk, a.S, item, s)) return;
     const int b = item / nblk, blk = item % nblk;
     const int x0 = (blk % tiles_x) * BT_W, y0 = (blk / tiles_x) * BT_H;
-    CamMats cam[F];
-    load_cams<F>(a, b, camS, cam);
     const size_t HW = (size_t)H * W;
     const float min_disp = 1.f / a.max_depth, max_disp = 1.f / a.min_depth;
     const float wm1 = (float)(W - 1), hm1 = (float)(H - 1), rw = 1.f / wm1, rh = 1.f / hm1;
@@ -336,54 +334,111 @@ __global__ __launch_bounds__(256) void photo_bwd_kernel(const md_photo_desc a, f
     // d loss_s / d (min * mask)[p] = gloss_s / (sum(mask) + 1e-7)
     const float gscale = a.gloss[s] ? a.gloss[s][0] / (a.loss[s * 2 + 1] + 1e-7f) : 0.f;
     const unsigned char *selb = a.sel[s] + (size_t)b * HW;
-
-    {
-        const float *tgt = a.target + (size_t)b * 3 * HW;
-#pragma unroll 1
-        for (int i = tid; i < B2_N; i += 256) {
-            const int py = clampi(reflect1(y0 - 2 + i / B2_W, H), 0, H - 1), px = clampi(reflect1(x0 - 2 + i % B2_W, W), 0, W - 1);
-            const size_t p = (size_t)py * W + px;
-            tg[i] = make_float4(tgt[p], tgt[HW + p], tgt[2 * HW + p], 0.f);
-#pragma unroll
-            for (int f = 0; f < F; ++f) {
-                const float *im = a.warped[s][f] + (size_t)b * 3 * HW;
-                wp[f * B2_N + i] = make_float4(im[p], im[HW + p], im[2 * HW + p], 0.f);
-            }
-        }
-    }
+    // a fractional external mask scales the gradient; the selection byte only carries mask != 0
+    const float *maskb = a.mask[s] ? a.mask[s] + (size_t)b * HW : nullptr;
     const int tx = tid % BT_W, ty = tid / BT_W;
     const int qx = x0 + tx, qy = y0 + ty;
     const bool qvalid = qx < W && qy < H;
     const size_t q = (size_t)qy * W + qx;
-    const unsigned char selq = qvalid ? selb[q] : 0;
-    // a fractional external mask scales the gradient; the selection byte only carries mask != 0
-    const float *maskb = a.mask[s] ? a.mask[s] + (size_t)b * HW : nullptr;
-    // geometry of the pixel, shared by the frames
-    float depth = 1.f, sd = 1.f, r0 = 0.f, r1 = 0.f, r2 = 0.f;
-    if (qvalid) {
-        md_ray(cam[0], (float)qx, (float)qy, r0, r1, r2);
-        if (a.is_disp) {
-            sd = disp_up_sd(a.dz[s] + (size_t)b * a.dh[s] * a.dw[s], a.dh[s], a.dw[s], H, W, qy, qx, min_disp, max_disp);
-            depth = 1.f / sd;
-        } else {
-            depth = a.dz[s][(size_t)b * HW + q];
+
+    // ---- Every global load whose address does not depend on another load is issued HERE, before the first barrier: the images
+    // with halo 2, the selection bytes of the thread's coefficient positions, the pixel's own byte, its disparity taps.  The
+    // kernel is bound by memory latency (its inputs were written a whole forward + 0.5 GB of cost-volume traffic ago: HBM, not
+    // the Infinity Cache); as first written it chained nine dependent round trips per workgroup (camera matrices -> two staging
+    // iterations -> per frame: selection bytes, then the twelve taps) and ran 316 us inside the training step.
+    constexpr int NST = (B2_N + 255) / 256, NCF = (B1_N + 255) / 256;
+    float4 st[NST][1 + F];
+    {
+        const float *tgt = a.target + (size_t)b * 3 * HW;
+#pragma unroll
+        for (int k = 0; k < NST; ++k) {
+            const int i = tid + 256 * k;   // clamped: the last round's surplus threads re-read position B2_N - 1
+            const int ii = i < B2_N ? i : B2_N - 1;
+            const int py = clampi(reflect1(y0 - 2 + ii / B2_W, H), 0, H - 1), px = clampi(reflect1(x0 - 2 + ii % B2_W, W), 0, W - 1);
+            const size_t p = (size_t)py * W + px;
+            st[k][0] = make_float4(tgt[p], tgt[HW + p], tgt[2 * HW + p], 0.f);
+#pragma unroll
+            for (int f = 0; f < F; ++f) {
+                const float *im = a.warped[s][f] + (size_t)b * 3 * HW;
+                st[k][1 + f] = make_float4(im[p], im[HW + p], im[2 * HW + p], 0.f);
+            }
         }
     }
+    unsigned char selc[NCF];
+    float mskc[NCF];
+#pragma unroll
+    for (int k = 0; k < NCF; ++k) {
+        const int i = tid + 256 * k;
+        const int py = y0 - 1 + i / B1_W, px = x0 - 1 + i % B1_W;
+        const bool in = i < B1_N && py >= 0 && py < H && px >= 0 && px < W;
+        const size_t p = in ? (size_t)py * W + px : 0;
+        selc[k] = selb[p];
+        mskc[k] = maskb ? maskb[p] : 1.f;
+        if (!in) selc[k] = 0;
+    }
+    const unsigned char selq = selb[qvalid ? q : 0];
+    const float maskq = maskb ? maskb[qvalid ? q : 0] : 1.f;
+    // geometry of the pixel, shared by the frames
+    float depth = 1.f, sd = 1.f;
+    {
+        const int cqy = qvalid ? qy : 0, cqx = qvalid ? qx : 0;
+        if (a.is_disp) {
+            sd = disp_up_sd(a.dz[s] + (size_t)b * a.dh[s] * a.dw[s], a.dh[s], a.dw[s], H, W, cqy, cqx, min_disp, max_disp);
+            depth = 1.f / sd;
+        } else {
+            depth = a.dz[s][(size_t)b * HW + (size_t)cqy * W + cqx];
+        }
+    }
+    CamMats cam[F];
+    load_cams<F>(a, b, camS, cam);   // (barrier inside)
+#pragma unroll
+    for (int k = 0; k < NST; ++k) {
+        const int i = tid + 256 * k;
+        if (i < B2_N) {
+            tg[i] = st[k][0];
+#pragma unroll
+            for (int f = 0; f < F; ++f) wp[f * B2_N + i] = st[k][1 + f];
+        }
+    }
+    float r0, r1, r2;
+    md_ray(cam[0], (float)qx, (float)qy, r0, r1, r2);
     float d_depth = 0.f;
     __syncthreads();
 
 #pragma unroll
     for (int f = 0; f < F; ++f) {
         const float4 *wf = wp + f * B2_N;
+        // ---- the frame's four bilinear taps: requested now, for every pixel whether or not a gradient will reach it, and used
+        // after the coefficient phase below -- their latency hides behind that phase's LDS work (deciding first which pixels
+        // need them would put the loads behind it again; keeping both frames' taps live cost a wave per SIMD in registers)
+        float tv[3][4];
+        float pzz, pu, pv, pgx, pgy, wx1, wy1;   // what the warp's backward needs of the projection
+        bool vx1, vy1;
+        {
+            const Proj pr = md_project_r(cam[f], r0, r1, r2, depth, wm1, hm1, rw, rh);
+            const Clip c = clip_border(pr.ix, pr.iy, W, H);
+            const Tap t = md_make_tap(c.ix, c.iy, W, H);
+            vx1 = t.x0 + 1 < W; vy1 = t.y0 + 1 < H;
+            const int x1 = vx1 ? t.x0 + 1 : t.x0, y1 = vy1 ? t.y0 + 1 : t.y0;   // unconditional loads, see sample_border
+            pzz = pr.zz; pu = pr.u; pv = pr.v; pgx = c.gmx; pgy = c.gmy; wx1 = t.wx1; wy1 = t.wy1;
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                const float *im = a.src[f] + ((size_t)b * 3 + ch) * HW;
+                tv[ch][0] = im[t.y0 * W + t.x0]; tv[ch][1] = im[t.y0 * W + x1];
+                tv[ch][2] = im[y1 * W + t.x0]; tv[ch][3] = im[y1 * W + x1];
+            }
+            __builtin_amdgcn_sched_barrier(0);   // keep the loads up here: the scheduler otherwise sinks them to their first use
+        }
         // ---- coefficient maps at halo 1, only where frame f is the selected minimum and the mask is set
         if (use_ssim) {
-#pragma unroll 1
-            for (int i = tid; i < B1_N; i += 256) {
+#pragma unroll
+            for (int k = 0; k < NCF; ++k) {
+                const int i = tid + 256 * k;
+                if (i >= B1_N) break;
                 const int cy = i / B1_W, cx = i % B1_W;
-                const int py = y0 - 1 + cy, px = x0 - 1 + cx;
                 float4 A = make_float4(0.f, 0.f, 0.f, 0.f), Bc = A, Cc = A;
-                if (py >= 0 && py < H && px >= 0 && px < W && selb[(size_t)py * W + px] == (unsigned char)(0x80 | f)) {
-                    const float gs = gscale * (maskb ? maskb[(size_t)py * W + px] : 1.f) * a.ssim_w / 3.f;
+                if (selc[k] == (unsigned char)(0x80 | f)) {
+                    const float gs = gscale * mskc[k] * a.ssim_w / 3.f;
                     float cA[3], cB[3], cC[3];
                     {
                         // each tap's float4 is read from LDS once for its three channels (read per channel, the kernel issued 400
@@ -446,7 +501,7 @@ __global__ __launch_bounds__(256) void photo_bwd_kernel(const md_photo_desc a, f
                 }
             }
             const float4 xq4 = wf[(ty + 2) * B2_W + tx + 2], yq4 = tg[(ty + 2) * B2_W + tx + 2];
-            const float gl1 = (selq == (unsigned char)(0x80 | f)) ? gscale * (maskb ? maskb[q] : 1.f) * wl1 / 3.f : 0.f;
+            const float gl1 = (selq == (unsigned char)(0x80 | f)) ? gscale * maskq * wl1 / 3.f : 0.f;
             float dpred[3];
             bool any = false;
 #pragma unroll
@@ -455,44 +510,32 @@ __global__ __launch_bounds__(256) void photo_bwd_kernel(const md_photo_desc a, f
                 const float diff = yq - xq;
                 const float sg = diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f);
                 float g = -sg * gl1;
-                if (use_ssim) g += (gA[c] + 2.f * gB[c] * xq + gC[c] * yq) / 9.f;
+                if (use_ssim) g += div9(gA[c] + 2.f * gB[c] * xq + gC[c] * yq);
                 dpred[c] = g;
                 any |= g != 0.f;
             }
             // ---- the warp's backward at q (warp.hip): gradients to the depth and to P = (K T)[:3]
             if (any) {
-                const Proj pr = md_project_r(cam[f], r0, r1, r2, depth, wm1, hm1, rw, rh);
-                const Clip c = clip_border(pr.ix, pr.iy, W, H);
-                const Tap t = md_make_tap(c.ix, c.iy, W, H);
-                const bool vx1 = t.x0 + 1 < W, vy1 = t.y0 + 1 < H;
-                const int x1 = vx1 ? t.x0 + 1 : t.x0, y1 = vy1 ? t.y0 + 1 : t.y0;   // unconditional loads, see sample_border
-                const float wx0 = 1.f - t.wx1, wy0 = 1.f - t.wy1;
+                const float wx0 = 1.f - wx1, wy0 = 1.f - wy1;
                 float gix = 0.f, giy = 0.f;
-                float tv[3][4];
-#pragma unroll
-                for (int ch = 0; ch < 3; ++ch) {
-                    const float *im = a.src[f] + ((size_t)b * 3 + ch) * HW;
-                    tv[ch][0] = im[t.y0 * W + t.x0]; tv[ch][1] = im[t.y0 * W + x1];
-                    tv[ch][2] = im[y1 * W + t.x0]; tv[ch][3] = im[y1 * W + x1];
-                }
 #pragma unroll
                 for (int ch = 0; ch < 3; ++ch) {
                     const float nw = tv[ch][0];
                     const float ne = vx1 ? tv[ch][1] : 0.f;
                     const float sw = vy1 ? tv[ch][2] : 0.f;
                     const float se = (vx1 && vy1) ? tv[ch][3] : 0.f;
-                    gix += dpred[ch] * ((ne - nw) * wy0 + (se - sw) * t.wy1);
-                    giy += dpred[ch] * ((sw - nw) * wx0 + (se - ne) * t.wx1);
+                    gix += dpred[ch] * ((ne - nw) * wy0 + (se - sw) * wy1);
+                    giy += dpred[ch] * ((sw - nw) * wx0 + (se - ne) * wx1);
                 }
-                const float du = gix * c.gmx * (2.f / (float)(W - 1));
-                const float dv = giy * c.gmy * (2.f / (float)(H - 1));
-                const float dc0 = du / pr.zz, dc1 = dv / pr.zz, dc2 = -(du * pr.u + dv * pr.v) / pr.zz;
+                const float du = gix * pgx * (2.f / (float)(W - 1));
+                const float dv = giy * pgy * (2.f / (float)(H - 1));
+                const float dc0 = du / pzz, dc1 = dv / pzz, dc2 = -(du * pu + dv * pv) / pzz;
                 const float a0 = cam[f].P[0] * r0 + cam[f].P[1] * r1 + cam[f].P[2] * r2;
                 const float a1 = cam[f].P[4] * r0 + cam[f].P[5] * r1 + cam[f].P[6] * r2;
                 const float a2 = cam[f].P[8] * r0 + cam[f].P[9] * r1 + cam[f].P[10] * r2;
                 d_depth += dc0 * a0 + dc1 * a1 + dc2 * a2;
                 if (a.d_T[f]) {
-                    const float Xh[4] = {pr.X, pr.Y, pr.Z, 1.f}, dc[3] = {dc0, dc1, dc2};
+                    const float Xh[4] = {depth * r0, depth * r1, depth * r2, 1.f}, dc[3] = {dc0, dc1, dc2};
 #pragma unroll
                     for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -501,18 +544,25 @@ __global__ __launch_bounds__(256) void photo_bwd_kernel(const md_photo_desc a, f
             }
         }
         if (a.d_T[f]) {
-            // partial sums of dL/dP: float inside each row of 16 lanes (neighbouring pixels), double across rows, waves, workgroups
-            // and scales -- the terms cancel across image regions.  DPP moves, no ds_bpermute: as __shfl_xor on doubles this was
-            // 288 LDS-crossbar instructions per wave and the kernel was LDS-bound (260 -> 171 us for the 4-scale backward).
+            // partial sums of dL/dP: float butterflies inside each row of 16 lanes (neighbouring pixels, DPP adds), the 16 row sums
+            // of the workgroup through LDS, summed in double by twelve threads (the terms cancel across image regions; as __shfl_xor
+            // on doubles this was 288 LDS-crossbar instructions per wave and the kernel LDS-bound, as all-DPP double sums a
+            // quarter of its VALU instructions)
 #pragma unroll
             for (int k = 0; k < 12; ++k) {
-                const double v = md_wave_sum_dpp_f16_d(dP[k]);
-                if (lane == 0) red[wave][k] = v;
+                float v = dP[k];
+#define MD_DPP_ADDF(ctrl) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xF, 0xF, false))
+                MD_DPP_ADDF(0xB1); MD_DPP_ADDF(0x4E); MD_DPP_ADDF(0x141); MD_DPP_ADDF(0x140);
+#undef MD_DPP_ADDF
+                if ((lane & 15) == 0) redf[(wave * 4 + (lane >> 4)) * 12 + k] = v;
             }
             __syncthreads();
-            if (tid < 12)
-                wsP[((((size_t)s * F + f) * a.B + b) * nblk + blk) * 12 + tid] =
-                    (float)(red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid]);
+            if (tid < 12) {
+                double acc = 0.0;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc += (double)redf[r * 12 + tid];
+                wsP[((((size_t)s * F + f) * a.B + b) * nblk + blk) * 12 + tid] = (float)acc;
+            }
         }
         __syncthreads();  // cf / red are reused by the next frame
     }

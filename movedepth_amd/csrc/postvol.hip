@@ -284,46 +284,80 @@ __global__ __launch_bounds__(256) void convex_up_fwd_kernel(const float *__restr
     out[((size_t)b * H + Y) * W + X] = acc;
 }
 
+// Backward, both gradients from one pass over the fine pixels.  A thread owns fine pixel (Y, X) of coarse cell (y, x) =
+// (Y / s, X / s): soft-max backward for d_mask, and its nine terms g * p[k] of the depth gradient -- tap k of every fine pixel of
+// cell (y, x) is coarse pixel (y + k/3 - 1, x + k%3 - 1).  The terms are summed over the cell's s x s fine pixels here (lanes of a
+// cell: shuffles; rows of a cell: LDS, fixed order) into cellsum[b][k][y][x]; convex_up_bwd_depth_kernel then gathers nine of them
+// per coarse pixel.  (Round 2 gathered straight from gout / mask: 9 x s^2 = 144 soft-max evaluations per coarse pixel on 46,080
+// threads, 185 us per step -- the longest kernel of the post-volume path.)
+// Block: 64 fine columns x max(4, s) fine rows = whole cells (s a power of two <= 16).
 __global__ __launch_bounds__(256) void convex_up_bwd_mask_kernel(const float *__restrict__ gout, const float *__restrict__ depth,
                                                                  const float *__restrict__ mask, int h, int w, int s,
-                                                                 float *__restrict__ d_mask) {
+                                                                 float *__restrict__ d_mask, float *__restrict__ cellsum) {
+    __shared__ float red[4][9][64];
     const int b = blockIdx.z, H = h * s, W = w * s;
-    const int X = blockIdx.x * 64 + (threadIdx.x & 63), Y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (X >= W || Y >= H) return;
-    const int x = X / s, j = X % s, y = Y / s, i = Y % s;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int rows = s > 4 ? s : 4;                 // fine rows of this block
+    const int X = blockIdx.x * 64 + lane, Y0 = blockIdx.y * rows;
     const size_t hw = (size_t)h * w, kstride = (size_t)s * s * hw;
-    const size_t base = ((size_t)b * 9 * s * s + (size_t)i * s + j) * hw + (size_t)y * w + x;
-    float p[9], v[9];
-    cu_softmax9(mask, base, kstride, p);
-    float dot = 0.f;
+    const int x = X / s, j = X % s;
+    float t[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) t[k] = 0.f;
+    for (int r = wave; r < rows; r += 4) {          // s <= 4: one row per wave; s = 8, 16: the rows of one cell row, 4 at a time
+        const int Y = Y0 + r;
+        if (X >= W || Y >= H) continue;
+        const int y = Y / s, i = Y % s;
+        const size_t base = ((size_t)b * 9 * s * s + (size_t)i * s + j) * hw + (size_t)y * w + x;
+        float p[9], v[9];
+        cu_softmax9(mask, base, kstride, p);
+        float dot = 0.f;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const int yy = y + k / 3 - 1, xx = x + k % 3 - 1;
+            v[k] = (yy >= 0 && yy < h && xx >= 0 && xx < w) ? depth[(size_t)b * hw + (size_t)yy * w + xx] : 0.f;
+            dot += p[k] * v[k];
+        }
+        const float g = gout[((size_t)b * H + Y) * W + X];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            d_mask[base + k * kstride] = g * p[k] * (v[k] - dot);  // softmax backward
+            t[k] += g * p[k];
+        }
+    }
+    // sum over the s lanes (fine columns) of a cell, then over the waves (fine rows) that share a cell row
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
-        const int yy = y + k / 3 - 1, xx = x + k % 3 - 1;
-        v[k] = (yy >= 0 && yy < h && xx >= 0 && xx < w) ? depth[(size_t)b * hw + (size_t)yy * w + xx] : 0.f;
-        dot += p[k] * v[k];
+        float a = t[k];
+        for (int o = 1; o < s; o <<= 1) a += __shfl_xor(a, o, 64);
+        red[wave][k][lane] = a;
     }
-    const float g = gout[((size_t)b * H + Y) * W + X];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) d_mask[base + k * kstride] = g * p[k] * (v[k] - dot);  // softmax backward
+    __syncthreads();
+    const int wpc = s >= 4 ? 4 : s;                 // waves per cell row (s = 1: each wave is its own cell row)
+    const int cells_x = 64 / s;                     // cells per wave along x
+    const int crows = 4 / wpc;                      // cell rows per block (s >= 4: 1)
+    for (int idx = threadIdx.x; idx < 9 * cells_x * crows; idx += 256) {
+        const int cx = idx % cells_x, k = (idx / cells_x) % 9, cr = idx / (cells_x * 9);
+        const int xc = blockIdx.x * cells_x + cx, yc = (s >= 4 ? blockIdx.y : blockIdx.y * crows + cr);
+        if (xc >= w || yc >= h) continue;
+        float a = 0.f;
+        for (int wv = 0; wv < wpc; ++wv) a += red[cr * wpc + wv][k][cx * s];
+        cellsum[((size_t)b * 9 + k) * hw + (size_t)yc * w + xc] = a;
+    }
 }
 
-__global__ __launch_bounds__(256) void convex_up_bwd_depth_kernel(const float *__restrict__ gout, const float *__restrict__ mask,
-                                                                  int h, int w, int s, float *__restrict__ d_depth) {
-    const int b = blockIdx.z, H = h * s, W = w * s;
+__global__ __launch_bounds__(256) void convex_up_bwd_depth_kernel(const float *__restrict__ cellsum, int h, int w,
+                                                                  float *__restrict__ d_depth) {
+    const int b = blockIdx.z;
     const int xx = blockIdx.x * 64 + (threadIdx.x & 63), yy = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (xx >= w || yy >= h) return;
-    const size_t hw = (size_t)h * w, kstride = (size_t)s * s * hw;
+    const size_t hw = (size_t)h * w;
     float acc = 0.f;
     // coarse pixel (yy,xx) is tap k of the fine pixels of coarse cell (y,x) = (yy - k/3 + 1, xx - k%3 + 1)
+#pragma unroll
     for (int k = 0; k < 9; ++k) {
         const int y = yy - (k / 3 - 1), x = xx - (k % 3 - 1);
-        if (y < 0 || y >= h || x < 0 || x >= w) continue;
-        for (int i = 0; i < s; ++i)
-            for (int j = 0; j < s; ++j) {
-                float p[9];
-                cu_softmax9(mask, ((size_t)b * 9 * s * s + (size_t)i * s + j) * hw + (size_t)y * w + x, kstride, p);
-                acc += gout[((size_t)b * H + y * s + i) * W + x * s + j] * p[k];
-            }
+        if (y >= 0 && y < h && x >= 0 && x < w) acc += cellsum[((size_t)b * 9 + k) * hw + (size_t)y * w + x];
     }
     d_depth[(size_t)b * hw + (size_t)yy * w + xx] = acc;
 }
@@ -380,16 +414,18 @@ extern "C" int md_convex_upsample_fwd(const float *depth, const float *mask, int
     return MD_OK;
 }
 
+extern "C" size_t md_convex_upsample_bwd_ws_bytes(int B, int h, int w) { return sizeof(float) * 9 * (size_t)B * h * w; }
+
 extern "C" int md_convex_upsample_bwd(const float *gout, const float *depth, const float *mask, int B, int h, int w,
-                                      int scale, float *d_depth, float *d_mask, md_stream_t stream) {
-    MD_REQUIRE(gout && depth && mask && d_depth && d_mask, "md_convex_upsample_bwd: null tensor");
+                                      int scale, float *d_depth, float *d_mask, void *ws, md_stream_t stream) {
+    MD_REQUIRE(gout && depth && mask && d_depth && d_mask && ws, "md_convex_upsample_bwd: null tensor");
     MD_REQUIRE(B > 0 && B <= 65535 && h > 0 && w > 0 && scale >= 0 && scale <= 4, "md_convex_upsample_bwd: bad dims");
-    const int s = 1 << scale;
-    hipLaunchKernelGGL(convex_up_bwd_mask_kernel, dim3(md_cdiv(w * s, 64), md_cdiv(h * s, 4), B), dim3(256), 0,
-                       (hipStream_t)stream, gout, depth, mask, h, w, s, d_mask);
+    const int s = 1 << scale, rows = s > 4 ? s : 4;
+    hipLaunchKernelGGL(convex_up_bwd_mask_kernel, dim3(md_cdiv(w * s, 64), md_cdiv(h * s, rows), B), dim3(256), 0,
+                       (hipStream_t)stream, gout, depth, mask, h, w, s, d_mask, (float *)ws);
     MD_CHECK_LAUNCH("md_convex_upsample_bwd(mask)");
     hipLaunchKernelGGL(convex_up_bwd_depth_kernel, dim3(md_cdiv(w, 64), md_cdiv(h, 4), B), dim3(256), 0, (hipStream_t)stream,
-                       gout, mask, h, w, s, d_depth);
+                       (const float *)ws, h, w, d_depth);
     MD_CHECK_LAUNCH("md_convex_upsample_bwd(depth)");
     return MD_OK;
 }

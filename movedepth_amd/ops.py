@@ -681,8 +681,9 @@ class _ConvexUpsample(torch.autograd.Function):
         B, h, w = depth.shape[0], depth.shape[-2], depth.shape[-1]
         g = g.contiguous().float()
         d_depth, d_mask = torch.empty_like(depth), torch.empty_like(mask)
+        ws = _ws(_lib.load().md_convex_upsample_bwd_ws_bytes(B, h, w), depth.device)
         _lib.call("md_convex_upsample_bwd", _p(g), _p(depth), _p(mask), B, h, w, ctx.scale, _p(d_depth), _p(d_mask),
-                  _stream())
+                  _p(ws), _stream())
         return d_depth, d_mask, None
 
 

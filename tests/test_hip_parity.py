@@ -552,6 +552,28 @@ def test_convex_upsample_vs_oracle(ops, oracle_lib):
     assert_close(host(ops.convex_upsample(dev(depth), dev(mask), 2)), oracle_lib.convex_upsample(depth, mask, 2), rtol=1e-5)
 
 
+@pytest.mark.parametrize("scale,h,w", [(0, 9, 21), (1, 13, 37), (2, 12, 50), (3, 6, 11), (2, 48, 160)])
+def test_convex_upsample_gradients_all_scales(ops, scale, h, w):
+    """Both gradients against autograd of the reference's expression (layers.py:200-214: softmax over 9 taps of a zero-padded 3x3
+    unfold) for every up-sampling factor, ragged sizes included: the backward reduces the depth gradient per coarse cell inside
+    the fine-pixel kernel, with a different block shape per factor."""
+    torch.manual_seed(scale * 7 + h)
+    B, s = 2, 2 ** scale
+    depth = (2 + 20 * torch.rand(B, h, w, device="cuda")).requires_grad_(True)
+    mask = torch.randn(B, 9 * s * s, h, w, device="cuda", requires_grad=True)
+    g = torch.randn(B, s * h, s * w, device="cuda")
+    up = ops.convex_upsample(depth, mask, scale)
+    (up * g).sum().backward()
+    d2, m2 = depth.detach().clone().double().requires_grad_(True), mask.detach().clone().double().requires_grad_(True)
+    p = torch.softmax(m2.view(B, 1, 9, s, s, h, w), 2)
+    taps = torch.nn.functional.unfold(d2[:, None], [3, 3], padding=1).view(B, 1, 9, 1, 1, h, w)
+    ref = (p * taps).sum(2).permute(0, 1, 4, 2, 5, 3).reshape(B, s * h, s * w)
+    (ref * g.double()).sum().backward()
+    assert_close(host(up), ref.detach().cpu().numpy(), rtol=1e-5)
+    assert_close(host(depth.grad), d2.grad.cpu().numpy(), rtol=2e-5, what="d_depth")
+    assert_close(host(mask.grad), m2.grad.cpu().numpy(), rtol=2e-5, what="d_mask")
+
+
 def test_standalone_geometry_modules_golden(ops):
     """BackprojectDepth / Project3D keep the reference's call signature (layers.py:556-621)."""
     from movedepth_amd.layers import BackprojectDepth, Project3D

@@ -27,7 +27,7 @@ for f in glob.glob("/tmp/pmcp_*/p_counter_collection.csv"):
         if not any(s in n for s in ("photo_", "up_adjoint")):
             continue
         grid = r.get("Grid_Size", "")
-        k = n.split("(")[0].split("::")[-1] + " grid=" + grid
+        k = n.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0] + " grid=" + grid
         agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
         dur[k].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 lines = ["# rocprofv3 --pmc, tools/bench_photo.py (B=6, 192x640, 2 source frames; grid = threads: the mono group is 4 scales, the MVS group 1)",
