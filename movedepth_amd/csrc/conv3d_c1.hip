@@ -504,7 +504,9 @@ __global__ __launch_bounds__(256) void conv3d_c1_bwd_weight_mfma_kernel(const fl
         auto xload = [&](int d, int g) -> float {  // raw: masked by xok when it is consumed
             const float *p0 = xb + (size_t)d * plane * 16 + xbase;  // two row pointers + immediate offsets when not ragged
             if (!RAGGED) return (g < 8 ? p0 : p0 + xrow)[(g & 7) * 64];
-            return p0[xok(g) ? (g >> 3) * xrow + (g & 7) * 64 : 0];
+            // a masked lane reads the plane's first voxel (always inside the tensor): p0 itself can lie past the image when the
+            // tile is ragged, and past the allocation for the last plane of the last sample
+            return xok(g) ? p0[(g >> 3) * xrow + (g & 7) * 64] : xb[(size_t)d * plane * 16 + m];
         };
         Ring R;
         R.init(lds, dm, ty0, tx0, wave, lane);

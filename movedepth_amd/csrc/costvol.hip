@@ -732,14 +732,17 @@ int launch_cl_inst(const CvPtrs &q, const CvDims &dm, hipStream_t stream) {
     if (nwg <= 0) {
         // resident workgroup slots of this kernel on this chip, queried once per instantiation (the query costs tens of
         // microseconds of host time per call: with it in every launch the kernel started ~15 us late inside the training step)
-        static long long slots = 0;
-        if (slots == 0) {
+        static long long slots_of[16] = {0};   // per device: a process may drive more than one GPU
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+        if (slots_of[dev] == 0) {
             int per_cu = 0;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64 * NW, 0) != hipSuccess || per_cu < 1) per_cu = 1;
-            int dev = 0, cus = 256;
-            if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-            slots = (long long)cus * per_cu;
+            int cus = 256;
+            (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+            slots_of[dev] = (long long)cus * per_cu;
         }
+        const long long slots = slots_of[dev];
         // k equal hypothesis slices per item, the smallest k that fills every slot at least once (>= 8 steps per slice):
         // item-aligned slices stage one window each; an arbitrary grid (e.g. exactly `slots`) makes most workgroups straddle
         // two items and stage twice (B=6, 48x160, D=96: 720 workgroups 67.8 us, 512 72.8 us, 1024 82.7 us)
@@ -768,7 +771,7 @@ int launch_cl_inst(const CvPtrs &q, const CvDims &dm, hipStream_t stream) {
             }
         }
     }
-    if (dm2.k1 > 0 && dm.D / dm2.k1 > ITV_MAX) dm2.k1 = 0;  // an item-aligned slice must fit the interval table: plain shares
+    if (dm2.k1 > 0 && (dm.D + dm2.k1 - 1) / dm2.k1 > ITV_MAX) dm2.k1 = 0;  // an item-aligned slice (up to ceil(D / k) steps) must fit the interval table: plain shares
     if (nwg > total) { nwg = total; dm2.k1 = 0; }
     if (nwg * ITV_MAX < total) { nwg = (total + ITV_MAX - 1) / ITV_MAX; dm2.k1 = 0; }  // a share fits the interval table
     const dim3 grid((unsigned)nwg), block(64 * NW);

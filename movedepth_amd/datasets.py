@@ -72,7 +72,21 @@ class KITTIRAWDataset(torch.utils.data.Dataset):
         self.frame_idxs, self.num_scales = list(frame_idxs), int(num_scales)
         self.is_train, self.img_ext = bool(is_train), img_ext
         self.K = KITTI_K
-        self.rng = np.random.default_rng(seed)
+        self.seed = int(seed)
+        self._rng, self._rng_key = None, None
+
+    @property
+    def rng(self):
+        """The augmentation generator, created lazily PER WORKER PROCESS AND EPOCH: a generator stored on the dataset at
+        construction is copied into every forked DataLoader worker (all workers then draw the same flips / jitters, and the
+        same ones again every epoch).  DataLoader gives each worker a distinct torch seed that also changes per epoch
+        (base_seed + worker_id) -- the stream the reference's `random` module is re-seeded from -- so key on it."""
+        info = torch.utils.data.get_worker_info()
+        key = (os.getpid(), None if info is None else info.seed)
+        if self._rng is None or key != self._rng_key:
+            entropy = [self.seed] if info is None else [self.seed, int(info.seed) & 0xFFFFFFFF, int(info.seed) >> 32]
+            self._rng, self._rng_key = np.random.default_rng(entropy), key
+        return self._rng
 
     def __len__(self):
         return len(self.filenames)

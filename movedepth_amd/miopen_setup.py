@@ -29,8 +29,8 @@ CACHE_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "miopen_cac
 def use_shipped_cache(rank=0):
     if not os.path.isdir(CACHE_DIR) or "MIOPEN_USER_DB_PATH" in os.environ:
         return False
-    priv = os.path.join(tempfile.gettempdir(), "movedepth_miopen_rank%d_%d" % (rank, os.getpid()))
     try:
+        priv = tempfile.mkdtemp(prefix="movedepth_miopen_rank%d_" % rank)   # private, unpredictable name, mode 0700
         shutil.copytree(CACHE_DIR, priv, dirs_exist_ok=True)
     except OSError:
         return False

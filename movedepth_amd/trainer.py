@@ -607,6 +607,12 @@ class Trainer:
         # a misspelt model name or a missing file raises, as upstream (KeyError / FileNotFoundError at trainer.py:861-866):
         # silently training from random weights is the worse failure
         if n not in self.models:
+            # names the reference knows but this configuration does not build ('up' without --convex_up, the pose networks under
+            # --load_pose; 'up' is in the reference's default --models_to_load): skipped with a note.  Anything else is a typo
+            # and raises, as upstream (KeyError at trainer.py:861)
+            if n in ("up", "pose_encoder", "pose"):
+                print("load_model: '%s' is not part of this configuration, skipped" % n)
+                return
             raise KeyError("--models_to_load: unknown model %r (have %s)" % (n, ", ".join(self.models)))
         path = os.path.join(folder, "{}.pth".format(n))
         if not os.path.isfile(path):

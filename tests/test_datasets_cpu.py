@@ -130,6 +130,33 @@ def test_loader_batches_and_shards(tmp_path):
     _check_contract(batch, batch=2)
 
 
+def test_augmentation_draws_differ_across_workers_and_epochs(tmp_path):
+    """DataLoader workers are forked copies of the dataset: a generator created at construction would give every worker the
+    same flip / jitter draws, and the same ones again every epoch (the reference uses python `random`, which DataLoader
+    re-seeds per worker and per epoch).  The generator is therefore created per worker from the worker's own seed."""
+    folder = _write_tree(str(tmp_path))
+    lines = ["%s 2 l" % folder] * 32
+
+    class Probe(datasets.KITTIRAWDataset):
+        def __getitem__(self, index):   # the draws themselves, without decoding images
+            info = torch.utils.data.get_worker_info()
+            return torch.tensor([info.id if info else -1] + [int(self.rng.integers(1 << 30)) for _ in range(2)])
+
+    ds = Probe(str(tmp_path), lines, H, W, FRAMES, 4, is_train=True, img_ext=".png", seed=5)
+    loader = torch.utils.data.DataLoader(ds, batch_size=4, num_workers=4, shuffle=False)
+    epochs = [torch.cat(list(loader)) for _ in range(2)]
+    for ep in epochs:
+        first = {}
+        for wid, a, b_ in ep.tolist():
+            first.setdefault(wid, (a, b_))
+        assert len(first) == 4 and len(set(first.values())) == 4          # four workers, four different first draws
+    assert not torch.equal(epochs[0][:, 1:], epochs[1][:, 1:])           # and a new sequence in the next epoch
+    # single-process use is reproducible from the seed
+    a = Probe(str(tmp_path), lines, H, W, FRAMES, 4, is_train=True, img_ext=".png", seed=5)[0]
+    b = Probe(str(tmp_path), lines, H, W, FRAMES, 4, is_train=True, img_ext=".png", seed=5)[0]
+    assert torch.equal(a, b)
+
+
 def test_synthetic_producer_honours_the_same_contract():
     item = make_inputs(2, H, W, FRAMES, seed=1)
     _check_contract(item, batch=2)

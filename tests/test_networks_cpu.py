@@ -57,3 +57,29 @@ def test_pose_and_upsample_layers_cpu():
     up = networks.convex_upsample_layer(feature_dim=32, scale=2)
     d = up(torch.rand(1, 16, 24), torch.rand(1, 32, 16, 24))
     assert d.shape[-2:] == (64, 96)
+
+
+def test_default_models_to_load_skips_models_this_configuration_does_not_build(tmp_path, capsys):
+    """--models_to_load defaults to the reference's list, which names 'up' (built only with --convex_up) and the pose networks
+    (absent under --load_pose): those are skipped with a note; a name outside the known set still raises, as upstream."""
+    import pytest
+    import torch
+
+    from movedepth_amd.options import MovedepthOptions
+    from movedepth_amd.trainer import Trainer
+
+    opt = MovedepthOptions().parse([])
+    assert "up" in opt.models_to_load
+    t = Trainer.__new__(Trainer)
+    t.opt = opt
+    t.models = {"reg3d": torch.nn.Linear(2, 2)}
+    torch.save(t.models["reg3d"].state_dict(), str(tmp_path / "reg3d.pth"))
+    t._load_one(str(tmp_path), "reg3d")
+    for n in ("up", "pose_encoder", "pose"):
+        t._load_one(str(tmp_path), n)          # not built here: skipped
+    assert "skipped" in capsys.readouterr().out
+    with pytest.raises(KeyError):
+        t._load_one(str(tmp_path), "pose, reg3d")
+    with pytest.raises(FileNotFoundError):
+        t.models["mono_depth"] = torch.nn.Linear(2, 2)
+        t._load_one(str(tmp_path), "mono_depth")
