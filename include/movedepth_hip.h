@@ -97,9 +97,10 @@ int md_costvol_bwd_f16(const uint16_t *gout, long long g_sb, long long g_sd, lon
 /* ---- frame-confidence fusion --------------------------------------------------------------
  * trainer.py:349-363: w_f = max_G softmax_G(mean_D vol_f); out = sum_f w_f vol_f / (1e-8 + sum_f w_f).
  * vols: N device pointers (host array) to grouped volumes addressed with (sb, sd, sg, sp) strides, as is out.
- * weights [N,B,h,w] may be NULL. */
+ * weights [N,B,h,w] may be NULL.  eval_mode != 0: the evaluation script's weight instead (evaluate_depth.py:236:
+ * soft-max over D of the mean over G, then max over D); forward only. */
 int md_fuse_fwd(const float *const *vols, int N, int B, int D, int G, int hw, long long sb, long long sd,
-                long long sg, long long sp, float *out, float *weights, md_stream_t stream);
+                long long sg, long long sp, int eval_mode, float *out, float *weights, md_stream_t stream);
 /* Autograd of md_fuse_fwd (the weights are not detached in the reference). d_vols: N pointers. */
 int md_fuse_bwd(const float *gout, const float *const *vols, int N, int B, int D, int G, int hw, long long sb,
                 long long sd, long long sg, long long sp, float *const *d_vols, md_stream_t stream);

@@ -28,7 +28,7 @@ SIGNATURES = {
     "md_costvol_bwd_bf16": (_i, [_vp, _ll, _ll, _ll, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "md_costvol_fwd_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _i, _i, _i, _vp, _ll, _ll, _ll, _ll, _vp]),
     "md_costvol_bwd_f16": (_i, [_vp, _ll, _ll, _ll, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
-    "md_fuse_fwd": (_i, [_vp, _i, _i, _i, _i, _i, _ll, _ll, _ll, _ll, _vp, _vp, _vp]),
+    "md_fuse_fwd": (_i, [_vp, _i, _i, _i, _i, _i, _ll, _ll, _ll, _ll, _i, _vp, _vp, _vp]),
     "md_fuse_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _ll, _ll, _ll, _ll, _vp, _vp]),
     "md_warp_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "md_warp_bwd_ws_bytes": (_sz, [_i, _i, _i]),

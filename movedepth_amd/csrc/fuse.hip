@@ -16,6 +16,7 @@ struct FuseArgs {
     const float *gout;
     float *out, *weights;
     int N, B, D, G, hw;
+    int eval_mode;  // 0: training weight (mean over D, soft-max over G); 1: evaluation weight (mean over G, soft-max over D)
     long long sb, sd, sg, sp;
 };
 
@@ -31,6 +32,18 @@ __device__ __forceinline__ void frame_weight(const float *v, const FuseArgs &a, 
     }
 }
 
+// the evaluation script's weight (evaluate_depth.py:236): cv.mean(2) is the mean over the G groups, the soft-max runs over D
+__device__ __forceinline__ void frame_weight_eval(const float *v, const FuseArgs &a, float &M, float &s) {
+    M = -INFINITY; s = 0.f;
+    for (int d = 0; d < a.D; ++d) {
+        float acc = 0.f;
+        for (int g = 0; g < a.G; ++g) acc += v[(size_t)d * a.sd + (size_t)g * a.sg];
+        const float m = acc / (float)a.G;
+        if (m > M) { s = s * expf(M - m) + 1.f; M = m; }
+        else s += expf(m - M);
+    }
+}
+
 __global__ __launch_bounds__(256) void fuse_fwd_kernel(FuseArgs a) {
     const int b = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x;
     if (p >= a.hw) return;
@@ -40,7 +53,8 @@ __global__ __launch_bounds__(256) void fuse_fwd_kernel(FuseArgs a) {
         wf[f] = 0.f;
         if (f < a.N) {
             float M, s; int am;
-            frame_weight(a.vol[f] + (size_t)b * a.sb + (size_t)p * a.sp, a, M, s, am);
+            if (a.eval_mode) frame_weight_eval(a.vol[f] + (size_t)b * a.sb + (size_t)p * a.sp, a, M, s);
+            else frame_weight(a.vol[f] + (size_t)b * a.sb + (size_t)p * a.sp, a, M, s, am);
             wf[f] = 1.f / s;
             wsum += wf[f];
             if (a.weights) a.weights[((size_t)f * a.B + b) * a.hw + p] = wf[f];
@@ -119,12 +133,12 @@ int fill(FuseArgs &a, const char *fn, const float *const *vols, int N, int B, in
 }  // namespace
 
 extern "C" int md_fuse_fwd(const float *const *vols, int N, int B, int D, int G, int hw, long long sb, long long sd,
-                           long long sg, long long sp, float *out, float *weights, md_stream_t stream) {
+                           long long sg, long long sp, int eval_mode, float *out, float *weights, md_stream_t stream) {
     FuseArgs a{};
     int rc = fill(a, "md_fuse_fwd", vols, N, B, D, G, hw, sb, sd, sg, sp);
     if (rc) return rc;
     MD_REQUIRE(out, "md_fuse_fwd: null output");
-    a.out = out; a.weights = weights;
+    a.out = out; a.weights = weights; a.eval_mode = eval_mode != 0;
     hipLaunchKernelGGL(fuse_fwd_kernel, dim3(md_cdiv(hw, 256), B), dim3(256), 0, (hipStream_t)stream, a);
     MD_CHECK_LAUNCH("md_fuse_fwd");
     return MD_OK;

@@ -52,16 +52,10 @@ def predict_depth(models, data, opt, vol_layout="ndhwc", details=False):
                                 opt.reg3d_c, prior=depth_prior, ndepth=opt.num_depth_bins, scale_fac=opt.depth_bin_fac,
                                 z_trans=z_trans, type="inverse", layout=vol_layout) for f in range(len(src_feats))]
     weights = []
-    if len(vols) == 1:
-        cor = vols[0]  # w/(1e-8 + w): identity to 1.6e-7
-    else:
-        wsum, cor = 1e-8, 0
-        for v in vols:  # evaluation-time confidence: softmax over D of the group mean (evaluate_depth.py:236)
-            w = torch.softmax(v.mean(2), dim=1).max(1)[0]
-            weights.append(w)
-            wsum = wsum + w
-            cor = cor + w.unsqueeze(1).unsqueeze(1) * v
-        cor = cor / wsum.unsqueeze(1).unsqueeze(1)
+    # one lookup frame: w/(1e-8 + w) is the identity to 1.6e-7; more: the evaluation-time confidence weights (soft-max over D of
+    # the group mean, evaluate_depth.py:236) and the weighted sum in one kernel
+    cor, wts = ops.fuse_volumes_eval(vols, layout=vol_layout)
+    weights = [] if wts is None else [wts[i] for i in range(len(vols))]
     logits = models["reg3d"](cor)
     depth_low, _, _ = ops.softmax_entropy_localmax(logits, 1 / hyp[:, -1], 1 / hyp[:, 0], opt.norm_radius)
     depth_mvs = models["up"](depth_low, ref_context) if opt.convex_up else depth_low

@@ -218,7 +218,7 @@ class _FuseVolumes(torch.autograd.Function):
         store = torch.empty_like(vs[0])
         weights = torch.empty(N, B, h, w, device=store.device, dtype=torch.float32)
         arr = (ctypes.c_void_p * N)(*[v.data_ptr() for v in vs])
-        _lib.call("md_fuse_fwd", arr, N, B, D, G, h * w, sb, sd, sg, sp, _p(store), _p(weights), _stream())
+        _lib.call("md_fuse_fwd", arr, N, B, D, G, h * w, sb, sd, sg, sp, 0, _p(store), _p(weights), _stream())
         ctx.save_for_backward(*vs)
         ctx.meta = (layout, N, B, D, G, h, w, sb, sd, sg, sp)
         ctx.mark_non_differentiable(weights)
@@ -247,6 +247,28 @@ def fuse_volumes(vols, layout="bgd", exact_single_frame=False):
         if not v.is_cuda:
             raise _lib.MovedepthHipError("cost volumes must be GPU tensors: the HIP path has no CPU fallback")
     return _FuseVolumes.apply(layout, *[v.float() for v in vols])
+
+
+def fuse_volumes_eval(vols, layout="bgd"):
+    """The evaluation script's fusion over lookup frames (reference evaluate_depth.py:225-243): the confidence weight is the
+    max over D of softmax_D(mean over G) -- not the training one -- one kernel, forward only -> (cor_feats, weights)."""
+    if len(vols) == 1:
+        return vols[0], None
+    with torch.no_grad():
+        N = len(vols)
+        B, D, G, h, w = vols[0].shape
+        vs, strides = [], None
+        for v in vols:
+            if not v.is_cuda:
+                raise _lib.MovedepthHipError("cost volumes must be GPU tensors: the HIP path has no CPU fallback")
+            st, strides = _vol_as_layout(v.float(), layout)
+            vs.append(st)
+        sb, sd, sg, sp = strides
+        store = torch.empty_like(vs[0])
+        weights = torch.empty(N, B, h, w, device=store.device, dtype=torch.float32)
+        arr = (ctypes.c_void_p * N)(*[v.data_ptr() for v in vs])
+        _lib.call("md_fuse_fwd", arr, N, B, D, G, h * w, sb, sd, sg, sp, 1, _p(store), _p(weights), _stream())
+    return _vol_logical(store, layout), weights
 
 
 # --------------------------------------------------------------------------- photometric warp

@@ -154,6 +154,16 @@ def fuse(vols):
     return out, wts
 
 
+def fuse_eval(vols):
+    """evaluate_depth.py:225-243 (weights: soft-max over D of the mean over G). -> (cor_feats, weights [N,B,h,w])"""
+    vols = [_c(v) for v in vols]
+    B, D, G, h, w = vols[0].shape
+    out = np.empty_like(vols[0])
+    wts = np.empty((len(vols), B, h, w), np.float32)
+    lib().mdo_fuse_eval_fwd(_ptr_array(vols), _i(len(vols)), _i(B), _i(D), _i(G), _i(h * w), _p(out), _p(wts))
+    return out, wts
+
+
 def fuse_bwd(gout, vols):
     vols = [_c(v) for v in vols]
     gout = _c(gout)

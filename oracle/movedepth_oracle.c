@@ -378,6 +378,42 @@ void mdo_fuse_fwd(const float *const *vols, int N, int B, int D, int G, int hw, 
     }
 }
 
+/* The evaluation script's fusion, evaluate_depth.py:225-243: cor_weight = softmax(cost_vols.mean(2), dim=1).max(1)[0] on a
+ * (B,D,G,h,w) volume, i.e. mean over G, soft-max over D (the training code, above, takes the mean over D and the soft-max
+ * over G: SURVEY App. B-7).  vols: N pointers [B,D,G,hw]; out [B,D,G,hw]; weights [N,B,hw] (may be NULL). */
+void mdo_fuse_eval_fwd(const float *const *vols, int N, int B, int D, int G, int hw, float *out, float *weights) {
+#pragma omp parallel for schedule(static)
+    for (int b = 0; b < B; ++b) {
+        float *wf = (float *)malloc(sizeof(float) * N);
+        float *m = (float *)malloc(sizeof(float) * D);
+        for (int p = 0; p < hw; ++p) {
+            float wsum = 1e-8f;
+            for (int f = 0; f < N; ++f) {
+                const float *v = vols[f] + (size_t)b * D * G * hw + p;
+                float mx = -INFINITY;
+                for (int d = 0; d < D; ++d) {
+                    float s = 0.f;
+                    for (int g = 0; g < G; ++g) s += v[((size_t)d * G + g) * hw];
+                    m[d] = s / (float)G; /* .mean(2) over G */
+                    if (m[d] > mx) mx = m[d];
+                }
+                float den = 0.f;
+                for (int d = 0; d < D; ++d) den += expf(m[d] - mx);
+                wf[f] = 1.f / den; /* softmax(dim=D).max(1) */
+                wsum += wf[f];
+                if (weights) weights[((size_t)f * B + b) * hw + p] = wf[f];
+            }
+            for (int d = 0; d < D; ++d)
+                for (int g = 0; g < G; ++g) {
+                    float acc = 0.f;
+                    for (int f = 0; f < N; ++f) acc += wf[f] * vols[f][(((size_t)b * D + d) * G + g) * hw + p];
+                    out[(((size_t)b * D + d) * G + g) * hw + p] = acc / wsum;
+                }
+        }
+        free(wf); free(m);
+    }
+}
+
 /* Autograd of mdo_fuse_fwd (the weights are NOT detached in the reference). d_vols: N pointers [B,D,G,hw]. */
 void mdo_fuse_bwd(const float *gout, const float *const *vols, int N, int B, int D, int G, int hw,
                   float *const *d_vols) {

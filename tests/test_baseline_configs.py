@@ -152,3 +152,18 @@ def test_config5_three_lookup_frames_fp16_velocity_guided(ops, oracle_lib):
         (cor * dev(gout)).sum().backward()
         for i in range(3):
             assert_close(host(vs[i].grad), exp_d[i], what="d_vol%d" % i)
+
+
+def test_evaluation_time_fusion_kernel_vs_oracle(ops, oracle_lib):
+    """md_fuse_fwd(eval_mode=1): the evaluation script's confidence weight (reference evaluate_depth.py:236, soft-max over D of
+    the mean over G) for two and three lookup frames, both volume layouts; eval_n2.npz pins the same kernel through the whole
+    evaluation forward (test_step_golden.py)."""
+    rng = np.random.default_rng(8)
+    for N in (2, 3):
+        vols = [rng.standard_normal((2, 12, 16, 9, 20)).astype(np.float32) for _ in range(N)]
+        exp, wts = oracle_lib.fuse_eval(vols)
+        for layout in ("bdg", "ndhwc"):
+            cor, w = ops.fuse_volumes_eval([dev(v) for v in vols], layout=layout)
+            assert_close(host(cor), exp, what="cor_feats (eval)")
+            for i in range(N):
+                assert_close(host(w[i]), wts[i], rtol=1e-5)

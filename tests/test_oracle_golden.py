@@ -206,3 +206,22 @@ def test_pose_matrix_with_gradients(oracle_lib):
         assert_close(da[:5], ref[:5], rtol=5e-6, what="d_axisangle" + k)
         assert_close(da[5:], ref[5:], rtol=1e-4, what="d_axisangle (tiny angle)" + k)
         assert_close(dt, g["d_translation" + k].reshape(-1, 3), rtol=1e-5, what="d_translation" + k)
+
+
+def test_eval_fusion_matches_the_reference_expression(oracle_lib):
+    """oracle.fuse_eval against the tensor expression of reference evaluate_depth.py:225-243 (softmax over D of the mean over G,
+    max over D; 1e-8 in the denominator), evaluated with torch on the CPU.  The whole evaluation forward of the reference,
+    which contains this fusion, is pinned by tests/golden/eval_n2.npz on the GPU path."""
+    import torch
+
+    rng = np.random.default_rng(3)
+    vols = [rng.standard_normal((2, 7, 4, 5, 6)).astype(np.float32) for _ in range(3)]
+    cor, w = oracle_lib.fuse_eval(vols)
+    wsum, acc = 1e-8, 0
+    for f, v in enumerate(vols):
+        t = torch.from_numpy(v)
+        cw = torch.softmax(t.mean(2), dim=1).max(1)[0]
+        assert_close(w[f], cw.numpy(), rtol=1e-6)
+        wsum = wsum + cw
+        acc = acc + cw.unsqueeze(1).unsqueeze(1) * t
+    assert_close(cor, (acc / wsum.unsqueeze(1).unsqueeze(1)).numpy(), rtol=1e-6)
