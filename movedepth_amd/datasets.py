@@ -8,16 +8,21 @@ What the reference's `MonoDataset.__getitem__` + `KITTIRAWDataset` hand to `Trai
   ("K", s), ("inv_K", s)                  (4, 4) float32: KITTI's normalised intrinsics (kitti_dataset.py:26-29) with row 0 times
                                           W // 2**s and row 1 times H // 2**s (integer division, mono_dataset.py:212-213),
                                           inv_K = pinv(K);
-  training only, each with probability 1/2 and the SAME draw for every frame of the item: horizontal flip; colour jitter
-  (brightness, contrast, saturation in [0.8, 1.2], hue in [-0.1, 0.1], applied in a random order) on "color_aug" only;
+  training only, each decided once per item with probability 1/2: horizontal flip of every frame; colour jitter (brightness,
+  contrast, saturation in [0.8, 1.2], hue in [-0.1, 0.1], in a random order) on "color_aug" only -- with fresh factors for
+  every image, as torchvision 0.8.2's ColorJitter.forward draws them (see ColorJitter below);
   an all-black frame keeps color_aug = color; a neighbouring frame missing on disk is replaced by the frame next to it.
 
 File layout: <data_path>/<folder>/image_0{2,3}/data/<frame:010d><ext>, split lines "<folder> <frame> <l|r>".
 Not produced: "depth_gt" (needs the velodyne projection of kitti_utils.py, out of scope: it is only read by the monitoring
-metrics) and ('relative_pose', f) (DVSO poses, `--load_pose`).  The random draws are this module's own (a numpy Generator):
-the reference draws through torchvision, whose stream cannot be matched without it; the distribution is the same.
+metrics) and ('relative_pose', f) (DVSO poses, `--load_pose`).  Random draws: the reference's generators in the reference's
+order (python `random`, numpy global, torch global); the logic half of the item -- key set, frame substitution at sequence
+ends, intrinsics, the two coins and the position of all three random streams after an item -- is pinned to the reference's own
+`MonoDataset.__getitem__` by tests/golden/loader.json (tools/gen_golden_loader.py); resized / jittered pixel values are not
+(they are torchvision's in the reference, which this image does not have).
 """
 import os
+import random
 
 import numpy as np
 import torch
@@ -45,23 +50,29 @@ def _shift_hue(img, h):
 
 
 class ColorJitter:
-    """One draw of (brightness, contrast, saturation, hue, order); calling it applies that draw to an image."""
+    """Colour jitter with the reference's random stream: `transforms.ColorJitter(...)` of torchvision 0.8.2 (the version the
+    reference pins, environment.yml:16) draws in forward(), i.e. AT EVERY CALL -- torch.randperm(4) for the order, then one
+    torch.tensor(1.0).uniform_(lo, hi) per operation as it comes up -- so although mono_dataset.py:104-109 says the same
+    augmentation is applied to every image of an item, each image (every frame, every scale) gets its own factors; only
+    the decision to augment at all is shared.  The same calls are made here, in the same order, on torch's global generator
+    (which DataLoader seeds per worker and epoch): same stream.  The pixel arithmetic below is PIL's (torchvision's PIL path is
+    PIL's ImageEnhance + an 8-bit HSV shift as well), not pinned by a fixture: torchvision is not in this image."""
 
-    def __init__(self, rng, brightness=(0.8, 1.2), contrast=(0.8, 1.2), saturation=(0.8, 1.2), hue=(-0.1, 0.1)):
-        self.b, self.c, self.s = (float(rng.uniform(*r)) for r in (brightness, contrast, saturation))
-        self.h = float(rng.uniform(*hue))
-        self.order = rng.permutation(4)
+    def __init__(self, brightness=(0.8, 1.2), contrast=(0.8, 1.2), saturation=(0.8, 1.2), hue=(-0.1, 0.1)):
+        self.ranges = (brightness, contrast, saturation, hue)
 
     def __call__(self, img):
-        for op in self.order:
+        for op in torch.randperm(4).tolist():
+            lo, hi = self.ranges[op]
+            factor = torch.tensor(1.0).uniform_(lo, hi).item()
             if op == 0:
-                img = ImageEnhance.Brightness(img).enhance(self.b)
+                img = ImageEnhance.Brightness(img).enhance(factor)
             elif op == 1:
-                img = ImageEnhance.Contrast(img).enhance(self.c)
+                img = ImageEnhance.Contrast(img).enhance(factor)
             elif op == 2:
-                img = ImageEnhance.Color(img).enhance(self.s)
+                img = ImageEnhance.Color(img).enhance(factor)
             else:
-                img = _shift_hue(img, self.h)
+                img = _shift_hue(img, factor)
         return img
 
 
@@ -72,21 +83,7 @@ class KITTIRAWDataset(torch.utils.data.Dataset):
         self.frame_idxs, self.num_scales = list(frame_idxs), int(num_scales)
         self.is_train, self.img_ext = bool(is_train), img_ext
         self.K = KITTI_K
-        self.seed = int(seed)
-        self._rng, self._rng_key = None, None
-
-    @property
-    def rng(self):
-        """The augmentation generator, created lazily PER WORKER PROCESS AND EPOCH: a generator stored on the dataset at
-        construction is copied into every forked DataLoader worker (all workers then draw the same flips / jitters, and the
-        same ones again every epoch).  DataLoader gives each worker a distinct torch seed that also changes per epoch
-        (base_seed + worker_id) -- the stream the reference's `random` module is re-seeded from -- so key on it."""
-        info = torch.utils.data.get_worker_info()
-        key = (os.getpid(), None if info is None else info.seed)
-        if self._rng is None or key != self._rng_key:
-            entropy = [self.seed] if info is None else [self.seed, int(info.seed) & 0xFFFFFFFF, int(info.seed) >> 32]
-            self._rng, self._rng_key = np.random.default_rng(entropy), key
-        return self._rng
+        self.seed = int(seed)   # kept for call compatibility: the draws come from the process-global generators, see __getitem__
 
     def __len__(self):
         return len(self.filenames)
@@ -103,8 +100,12 @@ class KITTIRAWDataset(torch.utils.data.Dataset):
         parts = self.filenames[index].split()
         folder = parts[0]
         frame_index, side = (int(parts[1]), parts[2]) if len(parts) == 3 else (0, None)
-        do_aug = self.is_train and self.rng.random() > 0.5
-        do_flip = self.is_train and self.rng.random() > 0.5
+        # the reference's draws, generator for generator and in its order (mono_dataset.py:160-166): python `random` for the two
+        # coins (DataLoader re-seeds it in every worker, every epoch), then numpy's global generator for the robust-training
+        # frame offsets, drawn whether or not they are used
+        do_aug = self.is_train and random.random() > 0.5
+        do_flip = self.is_train and random.random() > 0.5
+        np.random.choice([-3, -2, -1, 1, 2, 3], 4, False)
         native = {}
         for i in self.frame_idxs:
             try:
@@ -114,12 +115,25 @@ class KITTIRAWDataset(torch.utils.data.Dataset):
                     raise FileNotFoundError("cannot find frame %s: check --data_path / --png" %
                                             self.image_path(folder, frame_index, side))
                 native[i] = native[i - 1 if i > 0 else i + 1]  # sequence end: repeat the neighbour (mono_dataset.py:196-199)
-        jitter = ColorJitter(self.rng) if do_aug else (lambda im: im)
-        inputs = {}
+        jitter = ColorJitter() if do_aug else (lambda im: im)
+        # Resize every frame down the pyramid (scale s from scale s-1), then augment in the reference's ORDER of calls
+        # (mono_dataset.py:111-125 walks the dictionary in insertion order): the native-resolution frames first -- their augmented
+        # copies are deleted again at :226-228, but each call draws from torch's generator -- then frame by frame, scale by scale.
+        # An all-black image is not augmented (and draws nothing).
+        pyramid = {}
         for i in self.frame_idxs:
             img = native[i]
             for s in range(self.num_scales):
                 img = img.resize((self.width // 2 ** s, self.height // 2 ** s), Image.LANCZOS)  # from the previous scale
+                pyramid[(i, s)] = img
+        if do_aug:
+            for i in self.frame_idxs:
+                if np.asarray(native[i]).any():
+                    jitter(native[i])
+        inputs = {}
+        for i in self.frame_idxs:
+            for s in range(self.num_scales):
+                img = pyramid[(i, s)]
                 t = _to_tensor(img)
                 inputs[("color", i, s)] = t
                 inputs[("color_aug", i, s)] = t if float(t.sum()) == 0 else _to_tensor(jitter(img))
