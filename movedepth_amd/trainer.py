@@ -103,7 +103,7 @@ class Trainer:
         if opt.vol_layout != "auto":
             self.vol_layout = opt.vol_layout
         for k, m in self.models.items():
-            if opt.ddp and opt.sync_bn and not share_gpu:
+            if opt.ddp and opt.sync_bn:   # also with MD_SHARE_GPU=1: SyncBatchNorm runs over gloo on CUDA tensors
                 m = torch.nn.SyncBatchNorm.convert_sync_batchnorm(m)
             self.models[k] = m.to(self.device)
             if opt.nets2d_channels_last and k != "reg3d" and k not in opt.nets2d_channels_last_skip.split(","):
@@ -113,7 +113,7 @@ class Trainer:
         for m in self.models.values():
             for mod in m.modules():
                 if isinstance(mod, networks.FusedBNReLU3d):
-                    if opt.ddp and opt.sync_bn and not share_gpu:   # what convert_sync_batchnorm does for the others
+                    if opt.ddp and opt.sync_bn:   # what convert_sync_batchnorm does for the others
                         mod.sync_group = dist.group.WORLD
         if opt.bn_counter_on_host:
             # BatchNorm's num_batches_tracked += 1 is a GPU kernel per BatchNorm call (115 per step, ~0.5 ms) for a counter

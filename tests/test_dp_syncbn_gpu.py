@@ -1,0 +1,180 @@
+"""The DEFAULT data-parallel path of the trainer -- `--ddp --sync_bn 1`, what `bench.py --gpus N` runs (reference
+trainer.py:69-135: every sub-model through SyncBatchNorm.convert_sync_batchnorm + DistributedDataParallel) -- with two ranks of
+the real Trainer, one process each, both on cuda:0 over gloo (MD_SHARE_GPU=1; RCCL on a multi-GPU node, same torch.distributed
+calls).  torch.nn.SyncBatchNorm for every BatchNorm of the five networks, networks.FusedBNReLU3d.sync_group for the two fused
+full-resolution layers of the regulariser, --bn_counter_on_host left at its default.
+
+With synchronised statistics and equal shard sizes the two-rank step IS the single-process step on the concatenated batch,
+provided every rank normalises its loss over the same number of pixels: auto-masking is switched off for this test (each rank
+divides by its own mask sum) and both ranks draw the same erase rectangle.  Checked against that big-batch run:
+  * the gradients every rank holds after the all-reduce, per parameter, 1e-4 norm-wise (5e-4 for the handful of parameters whose
+    gradient is itself a 1e-4 residue of cancelling terms);
+  * BatchNorm running statistics after the step (library SyncBatchNorm layers and the fused layers);
+  * weights identical on both ranks after the optimizer step;
+  * the number of collectives of the step = gradient buckets + one per BatchNorm call in the forward (statistics) + one per
+    BatchNorm call in the backward: nothing else talks.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+ARGV = ["--height", "64", "--width", "128", "--num_depth_bins", "16", "--convex_up", "--weights_init", "scratch",
+        "--miopen_find", "0", "--automask_noise", "host", "--grad_bucket_mb", "8", "--learning_rate", "1e-3",
+        "--disable_automasking"]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _named(t):
+    return [(mn + "." + pn, p) for mn, m in t.models.items() for pn, p in m.named_parameters()]
+
+
+def _bn_buffers(t):
+    out = {}
+    for mn, m in t.models.items():
+        for bn, b in m.named_buffers():
+            if bn.endswith(("running_mean", "running_var")):
+                out[mn + "." + bn] = b.detach().float().cpu().numpy().copy()
+    return out
+
+
+def _worker(rank, world, port, q):
+    try:
+        sys.path.insert(0, ROOT)
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                          LOCAL_RANK=str(rank), MD_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        import torch.distributed as dist
+
+        from movedepth_amd import networks
+        from movedepth_amd.options import MovedepthOptions
+        from movedepth_amd.synthetic import make_inputs
+        from movedepth_amd.trainer import Trainer
+
+        torch.backends.cudnn.benchmark = False
+        torch.backends.cudnn.deterministic = True
+        opt = MovedepthOptions().parse(ARGV + ["--batch_size", "2", "--ddp"])     # --sync_bn 1 is the default
+        torch.manual_seed(50 + rank)
+        np.random.seed(50 + rank)
+        t = Trainer(opt)
+        t.set_train()
+        sync_layers = [m for net in t.models.values() for m in net.modules()
+                       if isinstance(m, torch.nn.SyncBatchNorm) or (isinstance(m, networks.FusedBNReLU3d) and m.sync_group is not None)]
+        n_plain = sum(isinstance(m, torch.nn.modules.batchnorm._BatchNorm) and not isinstance(m, torch.nn.SyncBatchNorm)
+                      for net in t.models.values() for m in net.modules())
+        bn_calls = {"n": 0}
+        for m in sync_layers:
+            m.register_forward_hook(lambda *_: bn_calls.__setitem__("n", bn_calls["n"] + 1))
+        counts = {"all_reduce": 0, "all_gather": 0}
+        orig = {k: getattr(dist, k) for k in ("all_reduce", "all_gather", "all_gather_into_tensor")}
+
+        def wrap(name, key):
+            def f(*a, **k):
+                counts[key] += 1
+                return orig[name](*a, **k)
+            return f
+
+        dist.all_reduce, dist.all_gather = wrap("all_reduce", "all_reduce"), wrap("all_gather", "all_gather")
+        dist.all_gather_into_tensor = wrap("all_gather_into_tensor", "all_gather")
+        shard = make_inputs(2, 64, 128, opt.frame_ids, seed=200 + rank, device=t.device)
+        torch.manual_seed(300)
+        np.random.seed(300)          # the same erase rectangle on every rank and in the big-batch run
+        t.train_step(dict(shard))
+        torch.cuda.synchronize()
+        for k, v in orig.items():
+            setattr(dist, k, v)
+        grads = {n: (p.grad.detach().float().cpu().numpy().copy() if p.grad is not None else None) for n, p in _named(t)}
+        weights = np.concatenate([p.detach().float().cpu().numpy().ravel() for _, p in _named(t)])
+        counters_on_host = all(m.num_batches_tracked.device.type == "cpu" for m in sync_layers)
+        q.put((rank, grads, _bn_buffers(t), weights, dict(counts), bn_calls["n"], len(t.grad_sync.buckets), len(sync_layers), n_plain,
+               counters_on_host, None))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:
+        import traceback
+        q.put((rank,) + (None,) * 9 + (traceback.format_exc(),))
+
+
+def _big_batch():
+    """The same step in one process on the concatenated batch, plain BatchNorm: what synchronised statistics must reproduce."""
+    sys.path.insert(0, ROOT)
+    from movedepth_amd.options import MovedepthOptions
+    from movedepth_amd.synthetic import make_inputs
+    from movedepth_amd.trainer import Trainer
+
+    torch.backends.cudnn.benchmark = False
+    torch.backends.cudnn.deterministic = True
+    opt = MovedepthOptions().parse(ARGV + ["--batch_size", "4"])
+    torch.manual_seed(50)            # rank 0's initial weights (the constructor's broadcast gives them to every rank)
+    np.random.seed(50)
+    t = Trainer(opt)
+    t.set_train()
+    shards = [make_inputs(2, 64, 128, opt.frame_ids, seed=200 + r, device=t.device) for r in range(2)]
+    batch = {k: torch.cat([s[k] for s in shards], 0) for k in shards[0]}
+    torch.manual_seed(300)
+    np.random.seed(300)
+    t.train_step(batch)
+    torch.cuda.synchronize()
+    grads = {n: (p.grad.detach().float().cpu().numpy().copy() if p.grad is not None else None) for n, p in _named(t)}
+    return grads, _bn_buffers(t)
+
+
+def test_default_ddp_path_with_synchronised_batchnorm_equals_the_big_batch_step():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=900) for _ in range(world)], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=120)
+    for r in res:
+        assert r[10] is None, r[10]
+    (_, ga, bna, wa, ca, calls_a, nb, nsync, nplain, host_a, _), (_, gb, bnb, wb, cb, calls_b, _, _, _, host_b, _) = res
+    assert nplain == 0 and nsync >= 60, (nplain, nsync)                 # every BatchNorm layer of the networks is synchronised
+    assert host_a and host_b                                             # --bn_counter_on_host survived the conversion
+    assert np.array_equal(wa, wb), "weights differ between the ranks after the step"
+    for n in ga:
+        assert (ga[n] is None) == (gb[n] is None) and (ga[n] is None or np.array_equal(ga[n], gb[n])), n
+    # collectives: one per gradient bucket, one per BatchNorm call forward (statistics) and one per call backward
+    assert calls_a == calls_b and calls_a >= 100, calls_a                # 115 BatchNorm calls per step (shared encoders run 2-4 times)
+    assert ca == cb, (ca, cb)
+    assert ca["all_reduce"] + ca["all_gather"] == nb + 2 * calls_a, (ca, nb, calls_a)
+
+    want_g, want_bn = _big_batch()
+
+    def rel(a, b):
+        return float(np.linalg.norm(a.astype(np.float64) - b) / (np.linalg.norm(b.astype(np.float64)) + 1e-30))
+
+    worst = []
+    gmax = max(float(np.abs(v).max()) for v in want_g.values() if v is not None)
+    for n, want in want_g.items():
+        if want is None:
+            assert ga[n] is None or float(np.abs(ga[n]).max()) == 0.0, n
+            continue
+        if float(np.abs(want).max()) < 1e-6 * gmax:
+            continue                      # a gradient that is itself rounding noise (e.g. a bias in front of a BatchNorm)
+        worst.append((rel(ga[n], want), n))
+    worst.sort(reverse=True)
+    print("worst parameter gradients vs the big-batch step:", [(n, "%.1e" % r) for r, n in worst[:5]])
+    total = rel(np.concatenate([ga[n].ravel() for _, n in worst]), np.concatenate([want_g[n].ravel() for _, n in worst]))
+    print("all gradients, norm-wise: %.2e" % total)
+    assert total <= 1e-4, total
+    assert worst[0][0] <= 5e-4, worst[:3]
+    bn_worst = max((rel(bna[k], want_bn[k]), k) for k in want_bn)
+    print("worst BatchNorm running statistic:", bn_worst)
+    assert bn_worst[0] <= 1e-4, bn_worst

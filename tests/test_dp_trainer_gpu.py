@@ -5,6 +5,7 @@ same torch.distributed calls).  Each rank runs one Trainer.train_step on its own
     (DP semantics of the reference: each rank normalises its own loss, SURVEY 8e);
   * the weights are identical on both ranks before and after the optimizer step;
   * the number of collectives in the step == the number of gradient buckets (no data-path collective).
+This file runs with --sync_bn 0 (local BatchNorm statistics); the default --ddp --sync_bn 1 path is tests/test_dp_syncbn_gpu.py.
 """
 import os
 import socket
@@ -41,7 +42,7 @@ def _worker(rank, world, port, q):
         torch.backends.cudnn.benchmark = False
         torch.backends.cudnn.deterministic = True
         opt = MovedepthOptions().parse(["--height", "64", "--width", "128", "--num_depth_bins", "16", "--batch_size", "2",
-                                        "--convex_up", "--weights_init", "scratch", "--miopen_find", "0", "--ddp",
+                                        "--convex_up", "--weights_init", "scratch", "--miopen_find", "0", "--ddp", "--sync_bn", "0",
                                         "--automask_noise", "host", "--grad_bucket_mb", "8", "--learning_rate", "1e-3"])
         torch.manual_seed(50 + rank)       # different initial weights per rank: the constructor's broadcast must fix that
         np.random.seed(50 + rank)
