@@ -26,6 +26,17 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (guides/MI355X_MICROARCH.md)
 
 
+def costvol_source_hash():
+    """SHA-256 over the sources the plane-sweep kernels are compiled from: the committed PMC summary (profiles/
+    costvol_fwd_pmc.json, tools/make_profiles.sh) is stamped with it, and is quoted as `roofline.traffic` only for the kernels
+    it was collected on."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("costvol_cl.inc", "costvol.hip", "md_common.hpp"):
+        h.update(open(os.path.join(ROOT, "movedepth_amd", "csrc", f), "rb").read())
+    return h.hexdigest()
+
+
 def costvol_fwd_bytes(B, C, G, h, w, D, fused, eb=4):
     """ref + src features, hypotheses (or the prior when the schedule is fused), grouped volume, K/invK/T;
     eb = bytes per feature / volume element (4, or 2 under --amp)."""
@@ -78,18 +89,74 @@ def cpu_baseline(opt):
             n += 1
         return (time.time() - t0) / n, n
 
-    all_threads = oracle.num_threads()
-    dt, n = timed(8.0, 50)
-    # the reference pins OMP / MKL to ONE thread per process (trainer.py:2-4): that figure too
+    # ONE thread: what the reference itself runs on (it pins OMP / MKL to one thread per process, trainer.py:2-4).  The oracle's
+    # OpenMP regions are per-op loops over samples / planes that do not scale at one sample (128 threads measured SLOWER than
+    # one in round 2), so no "all cores" figure is reported.
     oracle.set_num_threads(1)
-    dt1, n1 = timed(12.0, 3)
-    oracle.set_num_threads(all_threads)
-    return {"value": 1.0 / dt, "unit": "images/s (hot path only, no conv nets)", "cores": all_threads,
-            "kind": "port", "value_1_thread": 1.0 / dt1,
+    dt1, n1 = timed(15.0, 8)
+    return {"value": 1.0 / dt1, "unit": "images/s (hot path only, no conv nets)", "cores": 1, "kind": "port",
+            "ms_per_image": 1e3 * dt1,
             "sample": "1 sample (1/6 batch) of config 2: 2x cost volume fwd+bwd (48x160, D=%d, C=32->G=%d), 12x "
                       "warp+SSIM/L1 fwd+bwd at %dx%d, identity + smoothness losses; C oracle (a port of the reference's "
-                      "CPU path, not the product) with OpenMP: %d runs of %.2f s on %d threads, %d runs of %.2f s on 1 "
-                      "thread (what the reference's trainer.py:2-4 forces)" % (D, G, H, W, n, dt, all_threads, n1, dt1)}
+                      "CPU path, not the product), %d runs of %.2f s on 1 thread (what the reference's trainer.py:2-4 forces; "
+                      "%d hardware threads on this box)" % (D, G, H, W, n1, dt1, os.cpu_count() or 0)}
+
+
+def gpu_hot_path_ms_per_image(opt, device, iters=20):
+    """The SAME list of hot-path operations the cpu_baseline times (2x plane sweep forward + backward, the photometric groups
+    of one step forward + backward, identity and smoothness losses; no convolution networks), on the GPU at the workload's
+    batch size, in ms per image: the like-for-like figure beside cpu_baseline (the headline images/s includes the networks)."""
+    from movedepth_amd import ops
+
+    B, H, W, D, C, G = opt.batch_size, opt.height, opt.width, opt.num_depth_bins, 32, opt.reg3d_c
+    h, w = H // 4, W // 4
+    g = torch.Generator(device=device).manual_seed(0)
+    rnd = lambda *sh: torch.randn(*sh, device=device, generator=g)
+    uni = lambda *sh: torch.rand(*sh, device=device, generator=g)
+    ref, src = rnd(B, C, h, w).requires_grad_(True), rnd(B, C, h, w).requires_grad_(True)
+
+    def Kmat(hh, ww):
+        K = torch.tensor([[0.58 * ww, 0, 0.5 * ww, 0], [0, 1.92 * hh, 0.5 * hh, 0], [0, 0, 1, 0], [0, 0, 0, 1]], device=device)
+        return K.repeat(B, 1, 1), torch.linalg.pinv(K).repeat(B, 1, 1)
+
+    Kq, iKq = Kmat(h, w)
+    K0, iK0 = Kmat(H, W)
+    T = torch.eye(4, device=device).repeat(B, 1, 1)
+    T[:, 0, 3], T[:, 2, 3] = 0.05, 0.03
+    Ts = [T.clone().requires_grad_(True), T.clone().requires_grad_(True)]
+    prior = 2 + 20 * uni(B, 1, h, w)
+    target, srcs = uni(B, 3, H, W), [uni(B, 3, H, W), uni(B, 3, H, W)]
+    disps = [(0.02 + 0.3 * uni(B, 1, H >> s, W >> s)).requires_grad_(True) for s in range(4)]
+    imgs = [uni(B, 3, H >> s, W >> s) for s in range(4)]
+    depth = (2 + 20 * uni(B, H, W)).requires_grad_(True)
+    noise = rnd(4, B, 1, H, W) * 1e-5
+    gvol = None
+
+    def one_batch():
+        nonlocal gvol
+        for _ in range(2):  # plain + mask-augmented pass
+            vol = ops.costvol_grouped(ref, src, Kq, iKq, T, G, prior=prior, ndepth=D, scale_fac=0.3, layout="ndhwc")
+            if gvol is None:
+                gvol = torch.randn_like(vol)
+            vol.backward(gvol)
+        ident = ops.identity_loss(target, srcs)
+        mono = ops.photometric_loss(target, srcs, Ts, K0, iK0, disps, is_disp=True, ident_min=ident, noise=noise, want_pix=True)
+        sm = ops.smooth_losses(disps, imgs)
+        (sum(mono["loss"]) + sum(sm)).backward()
+        for kw in (dict(mvs_mode=True, want_oob=True, want_mask=True), dict(ssim_w=0.0, want_mask=True)):  # MVS, fused depth
+            out = ops.photometric_loss(target, srcs, [t.detach() for t in Ts], K0, iK0, [depth], **kw)
+            out["loss"][0].backward()
+
+    for _ in range(3):
+        one_batch()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        one_batch()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters / B
 
 
 def main():
@@ -203,10 +270,15 @@ def main():
         ach = fbytes / (kt["avg_us"] * 1e-6) / 1e9 if kt else None
         # HBM bytes per launch from the PMC counters are NOT measured in this run: they come from a separate rocprofv3 --pmc
         # pass (tools/pmc_costvol.sh) whose result is committed under profiles/; reported under its own key with provenance
-        traffic_profile = None
+        traffic_profile, traffic = None, None
         pmc = os.path.join(ROOT, "profiles", "costvol_fwd_pmc.json")
         if os.path.exists(pmc) and not sfx:   # the counter file was collected for the fp32 kernel
             traffic_profile = json.load(open(pmc))
+            # quoted as `traffic` only when the counters were collected on exactly these kernel sources
+            if traffic_profile.get("kernel_source_sha256") == costvol_source_hash():
+                traffic = traffic_profile.get("hbm_bytes_per_launch")
+            else:
+                traffic_profile["stale"] = "collected on other kernel sources (sha256 differs): not quoted as roofline.traffic"
         out = {
             "metric": "train-step images/sec at 192x640, D=96; cost-volume HBM GB/s vs roofline" if not a.trainer_args else
                       "train-step images/sec at %dx%d, D=%d; cost-volume HBM GB/s vs roofline" % (opt.height, opt.width, opt.num_depth_bins),
@@ -223,7 +295,7 @@ def main():
                        "global_batch": gb, "parallelism": "dp%d" % world, "final_loss": loss_val},
             "roofline": {"bound": "hbm", "kernel": "md_costvol_fwd%s (plane-sweep cost volume, fused schedule + group mean)" % sfx,
                          "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (ach / HBM_PEAK_GBS) if ach else None,
-                         "traffic": None, "traffic_from_profile": traffic_profile, "algorithmic_bytes_per_launch": fbytes,
+                         "traffic": traffic, "traffic_from_profile": traffic_profile, "algorithmic_bytes_per_launch": fbytes,
                          "timing": "HIP events inside libmovedepth_hip.so around the kernel launch (md_kernel_timing_*)",
                          "avg_launch_us": kt.get("avg_us"), "min_launch_us": kt.get("min_us"), "median_launch_us": kt.get("median_us"), "launches_timed": kt.get("launches"),
                          "bwd_avg_launch_us": times.get("md_costvol_bwd" + sfx, {}).get("avg_us")},
@@ -248,6 +320,12 @@ def main():
             out["reg3d_handoff_kernels"] = conv
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(opt)
+            if not a.trainer_args:
+                gpu_ms = gpu_hot_path_ms_per_image(opt, dev)
+                out["cpu_baseline"]["gpu_hot_path_ms_per_image"] = gpu_ms
+                out["cpu_baseline"]["gpu_hot_path_note"] = ("the same operations on the GPU (batch %d, wall time incl. launches): "
+                                                            "%.3f ms per image against %.0f ms on one host thread" %
+                                                            (opt.batch_size, gpu_ms, out["cpu_baseline"]["ms_per_image"]))
         # the library's bf16 / fp16 kernels printf diagnostics to stdout (C stdio, flushed at exit when stdout is a pipe):
         # push those out first so that the JSON is the last line
         import ctypes

@@ -26,6 +26,8 @@
 //               once per workgroup with global float atomics.
 #include <limits.h>
 
+#include <atomic>
+
 #include "md_common.hpp"
 
 // Element type of the feature maps (ref, src) and of the volume (out, gout); everything in between is fp32.
@@ -99,6 +101,10 @@ struct CvDims {
     // slices each, workgroups >= nc take 1/fsub of one of the remaining slices (see launch_cl_inst)
     int k1, nc, fsub;
     unsigned long long *stats;   // md_costvol_stats: per-launch counters (null: off)
+    // wide-window fallback (costvol_cl.inc): per-sample flags written by cv_mode_kernel; a kernel processes the samples whose
+    // flag equals its wmode (null: every sample)
+    const unsigned char *wflags;
+    int wmode;
     long long sb, sd, sg, sp;
 };
 
@@ -624,6 +630,7 @@ __global__ __launch_bounds__(256) void costvol_bwd_kernel(const io_t *__restrict
     const long long hi = total * (blockIdx.x + 1) / gridDim.x;
     Seg sg;
     while (next_segment(dm, lo, hi, sg)) {
+    if (dm.wflags && dm.wflags[sg.b] != dm.wmode) continue;   // the channels-last kernel takes this sample (launch_cl)
     for (int i = tid; i < CPW * WP; i += 256) gw[i] = 0.f;
     Walk<FUSED> wk;
     int b, gbase, p, d0, d1, ox, oy;
@@ -788,6 +795,13 @@ int launch_cl_inst(const CvPtrs &q, const CvDims &dm, hipStream_t stream) {
     return MD_OK;
 }
 
+// Ring of per-launch flag arrays for the wide-window fallback (device globals: no allocation; a slot is reused 64 launches later)
+constexpr int CV_FLAG_SLOTS = 64, CV_FLAG_MAXB = 1024;
+__device__ unsigned char g_cv_flags[CV_FLAG_SLOTS][CV_FLAG_MAXB];
+
+template <bool BWD>
+int launch_gen1(const CvPtrs &q, CvDims dm, hipStream_t stream, const char *tname);
+
 template <bool BWD>
 int launch_cl(const CvPtrs &q, CvDims dm, hipStream_t stream) {
     const int N = dm.C / dm.G, LPP = dm.G / 4, TW = 64 / LPP;
@@ -800,30 +814,66 @@ int launch_cl(const CvPtrs &q, CvDims dm, hipStream_t stream) {
     dm.items = dm.B * dm.tiles;
     dm.dbg = 0;
     dm.stats = md_stats_buffer();
+    dm.wflags = nullptr;
+    dm.wmode = 0;
+    // Wild-pose fallback, backward only (see cv_mode_kernel): a one-wave-per-sample pre-pass flags the samples whose taps would
+    // thrash the small window; this file's kernel skips them and the first-generation backward takes them in a second launch.
+    // With sane poses no sample is flagged and the second launch's workgroups exit at once (~5 us).  MD_COSTVOL_WILD=0 switches
+    // the mechanism off, =1 flags every sample.
+    const int wild_env = env_int("MD_COSTVOL_WILD", -1);
+    const bool wild_ok = BWD && wild_env != 0 && dm.B <= CV_FLAG_MAXB;
+    if (wild_ok) {
+        static std::atomic<unsigned> slot_ctr{0};
+        unsigned char *flags = nullptr;
+        MD_CHECK_HIP(hipGetSymbolAddress((void **)&flags, HIP_SYMBOL(g_cv_flags)));
+        flags += (size_t)(slot_ctr.fetch_add(1) % CV_FLAG_SLOTS) * CV_FLAG_MAXB;
+        // the backward's tile and window: 16 (or 32) x NW pixels + cl_bwd_hx x CL_BWD_HY cells
+        hipLaunchKernelGGL(cv_mode_kernel, dim3(dm.B), dim3(64), 0, stream, q.K, q.invK, q.pose, q.hyp, q.prior, q.ztrans, dm, TW, NW,
+                           TW + cl_bwd_hx(NW), NW + CL_BWD_HY, wild_env == 1 ? 1 : 0, flags);
+        MD_CHECK_LAUNCH("md_costvol_bwd (pose pre-pass)");
+        dm.wflags = flags;
+    }
 #define MD_CL_F(N_, LPP_)                                                                                        \
     do {                                                                                                         \
         if (NW == 4)                                                                                             \
-            return q.hyp ? launch_cl_inst<BWD, N_, LPP_, 4, false>(q, dm, stream)                                \
-                         : launch_cl_inst<BWD, N_, LPP_, 4, true>(q, dm, stream);                                \
-        return q.hyp ? launch_cl_inst<BWD, N_, LPP_, 8, false>(q, dm, stream)                                    \
-                     : launch_cl_inst<BWD, N_, LPP_, 8, true>(q, dm, stream);                                    \
+            rc = q.hyp ? launch_cl_inst<BWD, N_, LPP_, 4, false>(q, dm, stream)                                  \
+                       : launch_cl_inst<BWD, N_, LPP_, 4, true>(q, dm, stream);                                  \
+        else                                                                                                     \
+            rc = q.hyp ? launch_cl_inst<BWD, N_, LPP_, 8, false>(q, dm, stream)                                  \
+                       : launch_cl_inst<BWD, N_, LPP_, 8, true>(q, dm, stream);                                  \
     } while (0)
+    int rc = MD_EINVAL;
+    bool found = true;
     switch (N * 10 + LPP) {
-        case 14: MD_CL_F(1, 4);
-        case 24: MD_CL_F(2, 4);
-        case 44: MD_CL_F(4, 4);
-        case 12: MD_CL_F(1, 2);
-        case 22: MD_CL_F(2, 2);
-        case 42: MD_CL_F(4, 2);
+        case 14: MD_CL_F(1, 4); break;
+        case 24: MD_CL_F(2, 4); break;
+        case 44: MD_CL_F(4, 4); break;
+        case 12: MD_CL_F(1, 2); break;
+        case 22: MD_CL_F(2, 2); break;
+        case 42: MD_CL_F(4, 2); break;
+        default: found = false;
     }
 #undef MD_CL_F
-    md_set_error("costvol: no channels-last kernel for C=%d G=%d", dm.C, dm.G);
-    return MD_EINVAL;
+    if (!found) {
+        md_set_error("costvol: no channels-last kernel for C=%d G=%d", dm.C, dm.G);
+        return MD_EINVAL;
+    }
+    if (rc != MD_OK || !wild_ok) return rc;
+    dm.wmode = 1;
+    return launch_gen1<BWD>(q, dm, stream, MD_CV_STR(MD_CV_NAME(md_costvol_bwd_wild)));
 }
 
 template <bool BWD>
 int launch(const CvPtrs &q, CvDims dm, hipStream_t stream) {
+    dm.wflags = nullptr;
+    dm.wmode = 0;
     if (cl_eligible(dm, BWD ? (const void *)q.gout : (const void *)q.out)) return launch_cl<BWD>(q, dm, stream);
+    return launch_gen1<BWD>(q, dm, stream, BWD ? MD_CV_STR(MD_CV_NAME(md_costvol_bwd)) : MD_CV_STR(MD_CV_NAME(md_costvol_fwd)));
+}
+
+// First-generation kernels (planar volumes, other channel groupings; and the wild-pose samples of a channels-last backward)
+template <bool BWD>
+int launch_gen1(const CvPtrs &q, CvDims dm, hipStream_t stream, const char *tname) {
     const int N = dm.C / dm.G;
     if (N != 1 && N != 2 && N != 4 && N != 8) {
         md_set_error("costvol: unsupported channel grouping C=%d G=%d (C/G must be 1, 2, 4 or 8)", dm.C, dm.G);
@@ -892,7 +942,6 @@ int launch(const CvPtrs &q, CvDims dm, hipStream_t stream) {
                       ((uintptr_t)q.out % 16) == 0;
     (void)nhwc;
     bool launched = true;
-    const char *tname = BWD ? MD_CV_STR(MD_CV_NAME(md_costvol_bwd)) : MD_CV_STR(MD_CV_NAME(md_costvol_fwd));
     hipEvent_t ev0, ev1;
     md_timing_pair(tname, &ev0, &ev1);
 

@@ -257,6 +257,40 @@ def test_costvol_wide_coordinates_white_noise(ops, oracle_lib, w, h):
     assert_close(host(s.grad), exp_dsrc, what="d_src")
 
 
+def test_costvol_wild_poses_backward_fallback_vs_oracle(ops, oracle_lib):
+    """Poses of an untrained pose network (axis-angle ~ N(0, 0.3^2) rad, translation ~ N(0, 2^2)): md_costvol_bwd's pre-pass
+    flags the samples whose taps would thrash the channels-last kernel's window and hands them to the first-generation backward
+    in a second launch (csrc/costvol.hip launch_cl); one sample of the batch keeps a sane pose and stays on the normal kernel.
+    Volume and both gradients against the oracle (reference layers.py:778-794, zeros padding: no cliff in grid_sample)."""
+    rng = np.random.default_rng(77)
+    B, C, G, h, w, D = 3, 32, 16, 48, 160, 32
+    ref = smooth_field(rng, (B, C, h, w), 3, -1, 1)
+    src = smooth_field(rng, (B, C, h, w), 3, -1, 1)
+    K, invK = kitti_K(h, w, B)
+    prior = (2 + 20 * smooth_field(rng, (B, 1, h, w), 8, 0, 1)).astype(np.float32)
+    pose = rand_pose(oracle_lib, rng, B, 0.3, 2.0)
+    pose[1] = rand_pose(oracle_lib, rng, 1, 0.01, 0.05)[0]
+    hyp = oracle_lib.schedule_depth_range(prior, D, 0.3, None, "inverse")
+    gout = rng.standard_normal((B, D, G, h, w)).astype(np.float32)
+    exp = oracle_lib.costvol_grouped(ref, src, K, invK, hyp, pose, G)
+    exp_dref, exp_dsrc = oracle_lib.costvol_grouped_bwd(gout, ref, src, K, invK, hyp, pose)
+    ops.enable_library_kernel_timing(True)
+    try:
+        r, s = dev(ref, True), dev(src, True)
+        vol = ops.costvol_grouped(r, s, dev(K), dev(invK), dev(pose), G, prior=dev(prior), ndepth=D, scale_fac=0.3, layout="ndhwc")
+        assert_close(host(vol), exp, what="volume")
+        vol.backward(dev(gout))
+        torch.cuda.synchronize()
+        t = ops.library_kernel_times_us(["md_costvol_bwd", "md_costvol_bwd_wild"])
+    finally:
+        ops.enable_library_kernel_timing(False)
+    assert t["md_costvol_bwd"]["launches"] == 1 and t["md_costvol_bwd_wild"]["launches"] == 1
+    # the second launch did real work (two of three samples), i.e. it is not the empty launch of a sane batch
+    assert t["md_costvol_bwd_wild"]["avg_us"] > 3 * t["md_costvol_bwd"]["avg_us"] or t["md_costvol_bwd_wild"]["avg_us"] > 50, t
+    assert_close(host(r.grad), exp_dref, what="d_ref")
+    assert_close(host(s.grad), exp_dsrc, what="d_src")
+
+
 def test_costvol_full_size_properties(ops):
     """BASELINE config 2 size (B=6, 48x160, D=96, C=32, G=16): size-independent properties, beside the oracle comparison of
     the same launch above.

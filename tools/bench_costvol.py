@@ -61,6 +61,11 @@ def main():
         prior = torch.full((B, 1, h, w), float(os.environ.get("PRIOR_CONST", "8.0")), device=dev)
     pose = torch.eye(4, device=dev).repeat(B, 1, 1)
     pose[:, 0, 3], pose[:, 2, 3] = float(os.environ.get("POSE_TX", "0.05")), float(os.environ.get("POSE_TZ", "0.03"))
+    if os.environ.get("POSE_ROT"):   # "wild" poses of an untrained pose network: axis-angle ~ N(0, rot^2), translation ~ N(0, trans^2)
+        from movedepth_amd.layers import transformation_from_parameters
+        gen = torch.Generator(device=dev).manual_seed(7)
+        pose = transformation_from_parameters(torch.randn(B, 1, 3, device=dev, generator=gen) * float(os.environ["POSE_ROT"]),
+                                              torch.randn(B, 1, 3, device=dev, generator=gen) * float(os.environ.get("POSE_TRANS", "2.0")))
     hyp = ops.schedule_depth_range(prior, D, 0.3)
     kw = dict(prior=prior, ndepth=D, scale_fac=0.3) if a.fused else dict(depth_priors=hyp)
     vol = ops.costvol_grouped(ref, src, K, invK, pose, G, layout=a.layout, **kw)
@@ -104,7 +109,7 @@ def main():
     tb = time_fn(bwd, a.iters)
     torch.cuda.synchronize()
     sfx = {"f32": "", "bf16": "_bf16", "f16": "_f16"}[a.dtype]
-    lib_t = ops.library_kernel_times_us(["md_costvol_fwd" + sfx, "md_costvol_bwd" + sfx])
+    lib_t = ops.library_kernel_times_us(["md_costvol_fwd" + sfx, "md_costvol_bwd" + sfx, "md_costvol_bwd_wild" + sfx])
     ops.enable_library_kernel_timing(False)
     env = {k: v for k, v in os.environ.items() if k.startswith("MD_")}
     print("costvol B=%d %dx%d D=%d C=%d G=%d fused=%d layout=%s dtype=%s prior=%s env=%s" % (B, h, w, D, C, G, a.fused, a.layout, a.dtype, a.prior, env))
@@ -127,7 +132,7 @@ def main():
                   "(%.1f lanes each), wave-steps %d" % (nm, v[0], v[1], v[2], v[3], v[4], v[5] / max(v[4], 1), v[6]))
     for k, v in lib_t.items():
         nb = fbytes if "fwd" in k else bbytes
-        print("  kernel only (dispatch start/stop events inside the library) %-16s avg %7.1f us  min %7.1f us  %d launches  %.1f%% of 8 TB/s" % (
+        print("  kernel only (dispatch start/stop events inside the library) %-24s avg %7.1f us  min %7.1f us  %d launches  %.1f%% of 8 TB/s" % (
             k, v["avg_us"], v["min_us"], v["launches"], nb / v["avg_us"] / 1e3 / 80))
 
 
