@@ -158,7 +158,8 @@ int md_masked_min_bwd(const float *gloss, const float *reproj, const float *mask
  * loss[s] = sum(min * mask) / (sum(mask) + 1e-7).  Same arithmetic per step as md_disp_to_depth_up / md_warp /
  * md_reproj_loss / md_masked_min above, which remain for callers that want the pieces.
  *
- * All images [B,3,H,W]; maps [B,H,W] (= [B,1,H,W]); K, invK, T[f] [B,4,4].  NULL output pointers are skipped. */
+ * All images PACKED, [B,H,W,4] float (r, g, b, 0 per pixel: md_pack_rgbx converts [B,3,H,W] frames): target, src[f] and the
+ * warped[s][f] outputs; maps [B,H,W] (= [B,1,H,W]); K, invK, T[f] [B,4,4].  NULL output pointers are skipped. */
 #define MD_PHOTO_MAX_FRAMES 4
 #define MD_PHOTO_MAX_SCALES 4
 typedef struct md_photo_desc {
@@ -193,6 +194,8 @@ typedef struct md_photo_desc {
     float *d_dz[MD_PHOTO_MAX_SCALES];         /* gradient w.r.t. dz[s], same shape */
     float *d_T[MD_PHOTO_MAX_FRAMES];          /* [B,4,4] summed over scales, or NULL (T detached, trainer.py:499) */
 } md_photo_desc;
+/* [B,3,H,W] -> [B,H,W,4] for n <= 5 images in one launch (once per step and frame) */
+int md_pack_rgbx(const float *const *imgs, int n, int B, int H, int W, float *const *out, md_stream_t stream);
 size_t md_photo_fwd_ws_bytes(int B, int S, int H, int W);
 int md_photo_fwd(const md_photo_desc *desc, void *ws, md_stream_t stream);
 size_t md_photo_bwd_ws_bytes(int B, int S, int F, int H, int W, int is_disp);

@@ -46,6 +46,7 @@ SIGNATURES = {
     "md_photo_bwd_ws_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
     "md_photo_bwd": (_i, [_vp, _vp, _vp]),
     "md_photo_desc_bytes": (_sz, []),
+    "md_pack_rgbx": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "md_smooth_multi_ws_bytes": (_sz, [_i, _i]),
     "md_smooth_multi_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "md_smooth_multi_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),

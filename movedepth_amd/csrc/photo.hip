@@ -23,6 +23,13 @@
 //   The disparity gradient is then gathered through the adjoint of the bilinear up-sampling by up_adjoint_kernel (all scales
 //   in one launch); the dL/dP partials are summed in double and turned into dL/dT = K^T dP by a one-block-per-(frame, sample)
 //   finish.  Every reduction is two-stage in a fixed order: results are bit-reproducible.
+//
+// Image layout.  Every image these kernels touch -- target, source frames, the warped frames they write -- is PACKED: (B,H,W,4)
+// float, one 16-byte RGBx record per pixel (md_pack_rgbx converts the (B,3,H,W) input frames once per step).  With planar images
+// the forward issued 24 dword gathers + 3 target loads + 6 dword stores per halo position and the kernels were bound by the
+// vector-memory instruction rate (GRBM_TA_BUSY 90 % of the kernel, ~45 cycles per wave-level access); packed it is 8 + 1 + 2
+// 16-byte accesses.  A (B,3,H,W) view of a packed image (strides 4HW, 1, 4W, 4) is an ordinary torch tensor: that is what
+// outputs[("color", f, s)] holds.
 #include "md_photo.hpp"
 
 namespace {
@@ -40,34 +47,27 @@ struct Sample3 {
     float v[3];
 };
 
-// grid_sample(border, align_corners=True) of a 3-channel image at the clipped position (the forward of warp.hip).
-// All twelve loads are unconditional, from clamped addresses, and selected to zero afterwards: a load under a (divergent)
-// branch sits in its own basic block behind an s_waitcnt, which made the twelve taps twelve SERIAL memory round trips
-// (the 4-scale forward spent 72 % of its wave cycles parked; so does warp_fwd_kernel, 13 us for 0.7 M pixels).
-__device__ __forceinline__ Sample3 sample_border(const float *__restrict__ img, size_t HW, int W, int H, const Clip &c) {
+// grid_sample(border, align_corners=True) of a packed image at the clipped position (the forward of warp.hip).
+// The four loads are unconditional, from clamped addresses, and selected to zero afterwards: a load under a (divergent)
+// branch sits in its own basic block behind an s_waitcnt, which made the taps SERIAL memory round trips (the 4-scale forward
+// spent 72 % of its wave cycles parked; so does warp_fwd_kernel, 13 us for 0.7 M pixels).
+__device__ __forceinline__ Sample3 sample_border(const float4 *__restrict__ img, int W, int H, const Clip &c) {
     const Tap t = md_make_tap(c.ix, c.iy, W, H);
     const bool vx1 = t.x0 + 1 < W, vy1 = t.y0 + 1 < H;  // x0, y0 are in range after clipping
     const int x1 = vx1 ? t.x0 + 1 : t.x0, y1 = vy1 ? t.y0 + 1 : t.y0;
     const float wx0 = 1.f - t.wx1, wy0 = 1.f - t.wy1;
-    const int o00 = t.y0 * W + t.x0, o01 = t.y0 * W + x1, o10 = y1 * W + t.x0, o11 = y1 * W + x1;
-    float v[3][4];
-#pragma unroll
-    for (int ch = 0; ch < 3; ++ch) {
-        const float *im = img + ch * HW;
-        v[ch][0] = im[o00]; v[ch][1] = im[o01]; v[ch][2] = im[o10]; v[ch][3] = im[o11];
-    }
+    const float4 v00 = img[t.y0 * W + t.x0], v01 = img[t.y0 * W + x1], v10 = img[y1 * W + t.x0], v11 = img[y1 * W + x1];
     Sample3 o;
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
-        float a = v[ch][0] * (wy0 * wx0);   // explicit fma chain, as warp_fwd_kernel: bit-equal results
-        a = fmaf(vx1 ? v[ch][1] : 0.f, wy0 * t.wx1, a);
-        a = fmaf(vy1 ? v[ch][2] : 0.f, t.wy1 * wx0, a);
-        a = fmaf((vx1 && vy1) ? v[ch][3] : 0.f, t.wy1 * t.wx1, a);
+        float a = f4c(v00, ch) * (wy0 * wx0);   // explicit fma chain, as warp_fwd_kernel: bit-equal results
+        a = fmaf(vx1 ? f4c(v01, ch) : 0.f, wy0 * t.wx1, a);
+        a = fmaf(vy1 ? f4c(v10, ch) : 0.f, t.wy1 * wx0, a);
+        a = fmaf((vx1 && vy1) ? f4c(v11, ch) : 0.f, t.wy1 * t.wx1, a);
         o.v[ch] = a;
     }
     return o;
 }
-
 
 // Work item of this workgroup.  Workgroups are dealt round-robin to the 8 XCDs (block b -> XCD b % 8: observed, relied on for
 // speed only), each with its own 4 MB L2; the images of one call are 26 MB at config 2.  Every XCD therefore gets a
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void photo_fwd_kernel(const md_photo_desc a, f
     CamMats cam[F];
     if (!IDENT) load_cams<F>(a, b, camS, cam);
     const size_t HW = (size_t)H * W;
-    const float *tgt = a.target + (size_t)b * 3 * HW;
+    const float4 *tgt = reinterpret_cast<const float4 *>(a.target) + (size_t)b * HW;
     const float min_disp = 1.f / a.max_depth, max_disp = 1.f / a.min_depth;
     const float wm1 = (float)(W - 1), hm1 = (float)(H - 1), rw = 1.f / wm1, rh = 1.f / hm1;
 
@@ -138,13 +138,10 @@ __global__ __launch_bounds__(256) void photo_fwd_kernel(const md_photo_desc a, f
         const int gy = y0 - 1 + cy, gx = x0 - 1 + cx;
         const int py = clampi(reflect1(gy, H), 0, H - 1), px = clampi(reflect1(gx, W), 0, W - 1);
         const size_t p = (size_t)py * W + px;
-        tg[i] = make_float4(tgt[p], tgt[HW + p], tgt[2 * HW + p], 0.f);
+        tg[i] = tgt[p];
         if (IDENT) {
 #pragma unroll
-            for (int f = 0; f < F; ++f) {
-                const float *im = a.src[f] + (size_t)b * 3 * HW;
-                wp[f * FP_N + i] = make_float4(im[p], im[HW + p], im[2 * HW + p], 0.f);
-            }
+            for (int f = 0; f < F; ++f) wp[f * FP_N + i] = (reinterpret_cast<const float4 *>(a.src[f]) + (size_t)b * HW)[p];
         } else {
             // the pixel this thread also writes the per-pixel outputs of (the interior of the tile, inside the image)
             const bool own = cy >= 1 && cy <= FT_H && cx >= 1 && cx <= FT_W && gy < H && gx < W;
@@ -158,13 +155,11 @@ __global__ __launch_bounds__(256) void photo_fwd_kernel(const md_photo_desc a, f
             for (int f = 0; f < F; ++f) {
                 const Proj pr = md_project_r(cam[f], r0, r1, r2, depth, wm1, hm1, rw, rh);
                 const Clip c = clip_border(pr.ix, pr.iy, W, H);
-                const Sample3 o = sample_border(a.src[f] + (size_t)b * 3 * HW, HW, W, H, c);
-                wp[f * FP_N + i] = make_float4(o.v[0], o.v[1], o.v[2], 0.f);
+                const Sample3 o = sample_border(reinterpret_cast<const float4 *>(a.src[f]) + (size_t)b * HW, W, H, c);
+                const float4 o4 = make_float4(o.v[0], o.v[1], o.v[2], 0.f);
+                wp[f * FP_N + i] = o4;
                 if (own) {
-                    if (a.warped[s][f]) {
-                        float *w_ = a.warped[s][f] + (size_t)b * 3 * HW + p;
-                        w_[0] = o.v[0]; w_[HW] = o.v[1]; w_[2 * HW] = o.v[2];
-                    }
+                    if (a.warped[s][f]) (reinterpret_cast<float4 *>(a.warped[s][f]) + (size_t)b * HW)[p] = o4;
                     if (a.pix[s][f]) *reinterpret_cast<float2 *>(a.pix[s][f] + ((size_t)b * HW + p) * 2) = make_float2(pr.gx, pr.gy);
                     if (s == 0 && a.oob[f])
                         a.oob[f][(size_t)b * HW + p] = (pr.gx < -1.f || pr.gx > 1.f || pr.gy < -1.f || pr.gy > 1.f) ? 1 : 0;
@@ -311,8 +306,9 @@ __global__ __launch_bounds__(256) void photo_fwd_finish_kernel(const float *__re
 }
 
 // ------------------------------------------------------------------------------------------------ backward
+// three waves per SIMD (<= 168 registers) for up to two source frames, two beyond
 template <int F>
-__global__ __launch_bounds__(256) void photo_bwd_kernel(const md_photo_desc a, float *__restrict__ gup, float *__restrict__ wsP) {
+__global__ __launch_bounds__(256, (F <= 2 ? 3 : 2)) void photo_bwd_kernel(const md_photo_desc a, float *__restrict__ gup, float *__restrict__ wsP) {
     extern __shared__ float4 lds[];
     float4 *tg = lds;                         // target, halo 2
     float4 *wp = lds + B2_N;                  // wp[f * B2_N + i]: warped frame f, halo 2
@@ -347,21 +343,19 @@ __global__ __launch_bounds__(256) void photo_bwd_kernel(const md_photo_desc a, f
     // the Infinity Cache); as first written it chained nine dependent round trips per workgroup (camera matrices -> two staging
     // iterations -> per frame: selection bytes, then the twelve taps) and ran 316 us inside the training step.
     constexpr int NST = (B2_N + 255) / 256, NCF = (B1_N + 255) / 256;
-    float4 st[NST][1 + F];
+    using v4f = float __attribute__((ext_vector_type(4)));   // a first-class vector: an array of HIP's float4 structs stayed in scratch
+    v4f st[NST][1 + F];
     {
-        const float *tgt = a.target + (size_t)b * 3 * HW;
+        const v4f *tgt = reinterpret_cast<const v4f *>(a.target) + (size_t)b * HW;
 #pragma unroll
         for (int k = 0; k < NST; ++k) {
             const int i = tid + 256 * k;   // clamped: the last round's surplus threads re-read position B2_N - 1
             const int ii = i < B2_N ? i : B2_N - 1;
             const int py = clampi(reflect1(y0 - 2 + ii / B2_W, H), 0, H - 1), px = clampi(reflect1(x0 - 2 + ii % B2_W, W), 0, W - 1);
             const size_t p = (size_t)py * W + px;
-            st[k][0] = make_float4(tgt[p], tgt[HW + p], tgt[2 * HW + p], 0.f);
+            st[k][0] = tgt[p];
 #pragma unroll
-            for (int f = 0; f < F; ++f) {
-                const float *im = a.warped[s][f] + (size_t)b * 3 * HW;
-                st[k][1 + f] = make_float4(im[p], im[HW + p], im[2 * HW + p], 0.f);
-            }
+            for (int f = 0; f < F; ++f) st[k][1 + f] = (reinterpret_cast<const v4f *>(a.warped[s][f]) + (size_t)b * HW)[p];
         }
     }
     unsigned char selc[NCF];
@@ -395,9 +389,9 @@ __global__ __launch_bounds__(256) void photo_bwd_kernel(const md_photo_desc a, f
     for (int k = 0; k < NST; ++k) {
         const int i = tid + 256 * k;
         if (i < B2_N) {
-            tg[i] = st[k][0];
+            reinterpret_cast<v4f *>(tg)[i] = st[k][0];
 #pragma unroll
-            for (int f = 0; f < F; ++f) wp[f * B2_N + i] = st[k][1 + f];
+            for (int f = 0; f < F; ++f) reinterpret_cast<v4f *>(wp)[f * B2_N + i] = st[k][1 + f];
         }
     }
     float r0, r1, r2;
@@ -411,7 +405,7 @@ __global__ __launch_bounds__(256) void photo_bwd_kernel(const md_photo_desc a, f
         // ---- the frame's four bilinear taps: requested now, for every pixel whether or not a gradient will reach it, and used
         // after the coefficient phase below -- their latency hides behind that phase's LDS work (deciding first which pixels
         // need them would put the loads behind it again; keeping both frames' taps live cost a wave per SIMD in registers)
-        float tv[3][4];
+        float4 tv0, tv1, tv2, tv3;               // north-west, north-east, south-west, south-east
         float pzz, pu, pv, pgx, pgy, wx1, wy1;   // what the warp's backward needs of the projection
         bool vx1, vy1;
         {
@@ -421,12 +415,8 @@ __global__ __launch_bounds__(256) void photo_bwd_kernel(const md_photo_desc a, f
             vx1 = t.x0 + 1 < W; vy1 = t.y0 + 1 < H;
             const int x1 = vx1 ? t.x0 + 1 : t.x0, y1 = vy1 ? t.y0 + 1 : t.y0;   // unconditional loads, see sample_border
             pzz = pr.zz; pu = pr.u; pv = pr.v; pgx = c.gmx; pgy = c.gmy; wx1 = t.wx1; wy1 = t.wy1;
-#pragma unroll
-            for (int ch = 0; ch < 3; ++ch) {
-                const float *im = a.src[f] + ((size_t)b * 3 + ch) * HW;
-                tv[ch][0] = im[t.y0 * W + t.x0]; tv[ch][1] = im[t.y0 * W + x1];
-                tv[ch][2] = im[y1 * W + t.x0]; tv[ch][3] = im[y1 * W + x1];
-            }
+            const float4 *im = reinterpret_cast<const float4 *>(a.src[f]) + (size_t)b * HW;
+            tv0 = im[t.y0 * W + t.x0]; tv1 = im[t.y0 * W + x1]; tv2 = im[y1 * W + t.x0]; tv3 = im[y1 * W + x1];
             __builtin_amdgcn_sched_barrier(0);   // keep the loads up here: the scheduler otherwise sinks them to their first use
         }
         // ---- coefficient maps at halo 1, only where frame f is the selected minimum and the mask is set
@@ -520,10 +510,10 @@ __global__ __launch_bounds__(256) void photo_bwd_kernel(const md_photo_desc a, f
                 float gix = 0.f, giy = 0.f;
 #pragma unroll
                 for (int ch = 0; ch < 3; ++ch) {
-                    const float nw = tv[ch][0];
-                    const float ne = vx1 ? tv[ch][1] : 0.f;
-                    const float sw = vy1 ? tv[ch][2] : 0.f;
-                    const float se = (vx1 && vy1) ? tv[ch][3] : 0.f;
+                    const float nw = f4c(tv0, ch);
+                    const float ne = vx1 ? f4c(tv1, ch) : 0.f;
+                    const float sw = vy1 ? f4c(tv2, ch) : 0.f;
+                    const float se = (vx1 && vy1) ? f4c(tv3, ch) : 0.f;
                     gix += dpred[ch] * ((ne - nw) * wy0 + (se - sw) * wy1);
                     giy += dpred[ch] * ((sw - nw) * wx0 + (se - ne) * wx1);
                 }
@@ -661,6 +651,24 @@ __global__ __launch_bounds__(256) void up_adjoint_kernel(const md_photo_desc a, 
     if (live && sub == 0) a.d_dz[s][((size_t)b * h + iy) * w + ix] = acc;
 }
 
+// (B,3,H,W) -> (B,H,W,4), up to MAXF + 1 images per launch
+struct PackArgs {
+    const float *in[MAXF + 1];
+    float *out[MAXF + 1];
+    int n;
+    long long BHW, HW;
+};
+__global__ __launch_bounds__(256) void pack_rgbx_kernel(const PackArgs a) {
+    const int k = blockIdx.y;
+    const float *in = a.in[k];
+    float4 *out = reinterpret_cast<float4 *>(a.out[k]);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < a.BHW; i += (long long)gridDim.x * 256) {
+        const long long b = i / a.HW, p = i - b * a.HW;
+        const float *px = in + b * 3 * a.HW + p;
+        out[i] = make_float4(px[0], px[a.HW], px[2 * a.HW], 0.f);
+    }
+}
+
 int check_desc(const char *fn, const md_photo_desc *d) {
     MD_REQUIRE(d, "%s: null descriptor", fn);
     MD_REQUIRE(d->B > 0 && d->B <= 4096 && d->H >= 3 && d->W >= 3, "%s: bad dims B=%d H=%d W=%d (H, W >= 3)", fn, d->B, d->H, d->W);
@@ -682,6 +690,21 @@ int check_desc(const char *fn, const md_photo_desc *d) {
 }  // namespace
 
 extern "C" size_t md_photo_desc_bytes(void) { return sizeof(md_photo_desc); }
+
+extern "C" int md_pack_rgbx(const float *const *imgs, int n, int B, int H, int W, float *const *out, md_stream_t stream) {
+    MD_REQUIRE(imgs && out && n >= 1 && n <= MAXF + 1, "md_pack_rgbx: 1..%d images", MAXF + 1);
+    MD_REQUIRE(B > 0 && H > 0 && W > 0, "md_pack_rgbx: bad dims");
+    PackArgs a{};
+    for (int k = 0; k < n; ++k) {
+        MD_REQUIRE(imgs[k] && out[k], "md_pack_rgbx: null image %d", k);
+        a.in[k] = imgs[k];
+        a.out[k] = out[k];
+    }
+    a.n = n; a.HW = (long long)H * W; a.BHW = a.HW * B;
+    hipLaunchKernelGGL(pack_rgbx_kernel, dim3((unsigned)md_cdiv(a.BHW, 256 * 2), n), dim3(256), 0, (hipStream_t)stream, a);
+    MD_CHECK_LAUNCH("md_pack_rgbx");
+    return MD_OK;
+}
 
 extern "C" size_t md_photo_fwd_ws_bytes(int B, int S, int H, int W) {
     return sizeof(float) * 2 * (size_t)B * S * md_cdiv(W, FT_W) * md_cdiv(H, FT_H);

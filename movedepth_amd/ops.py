@@ -414,8 +414,46 @@ def _ptr(t):
     return None if t is None else t.data_ptr()
 
 
+def is_packed(img):
+    """(B,H,W,4) contiguous float32 RGBx: the image layout of the fused photometric kernels"""
+    return img.dim() == 4 and img.shape[-1] == 4 and img.shape[1] != 3 and img.dtype == torch.float32 and img.is_contiguous()
+
+
+def packed_view(p):
+    """(B,3,H,W) view of a packed (B,H,W,4) image: strides (4HW, 1, 4W, 4), no copy"""
+    return p[..., :3].permute(0, 3, 1, 2)
+
+
+def pack_rgbx(imgs):
+    """(B,3,H,W) frames -> packed (B,H,W,4) RGBx, up to five images per launch (md_pack_rgbx).  no_grad: the frames are inputs."""
+    imgs = list(imgs)
+    out = []
+    with torch.no_grad():
+        for i in range(0, len(imgs), 5):
+            chunk = [_prep(t, "image") for t in imgs[i:i + 5]]
+            B, Ci, H, W = chunk[0].shape
+            if Ci != 3 or any(tuple(t.shape) != (B, 3, H, W) for t in chunk):
+                raise _lib.MovedepthHipError("pack_rgbx: images must be (B,3,H,W) of one size")
+            res = [torch.empty(B, H, W, 4, device=chunk[0].device, dtype=torch.float32) for _ in chunk]
+            n = len(chunk)
+            _lib.call("md_pack_rgbx", (ctypes.c_void_p * n)(*[t.data_ptr() for t in chunk]), n, B, H, W,
+                      (ctypes.c_void_p * n)(*[t.data_ptr() for t in res]), _stream())
+            out += res
+    return out
+
+
+def _packed(imgs):
+    """accept planar (B,3,H,W) or packed (B,H,W,4) images; pack the planar ones (one launch)"""
+    imgs = list(imgs)
+    todo = [i for i, t in enumerate(imgs) if not is_packed(t)]
+    if todo:
+        for i, p in zip(todo, pack_rgbx([imgs[i] for i in todo])):
+            imgs[i] = p
+    return imgs
+
+
 def _fill_desc(d, cfg, target, srcs, Ts, K, invK, dzs, ident_min, noise, ext_mask):
-    B, _, H, W = target.shape
+    B, H, W, _ = target.shape     # packed (B,H,W,4)
     d.B, d.H, d.W, d.F, d.S = B, H, W, len(srcs), len(dzs)
     d.is_disp, d.identity, d.mvs_mode, d.no_ssim = int(cfg["is_disp"]), int(cfg["identity"]), int(cfg["mvs_mode"]), int(cfg["no_ssim"])
     d.ssim_w, d.min_depth, d.max_depth = float(cfg["ssim_w"]), float(cfg["min_depth"]), float(cfg["max_depth"])
@@ -436,14 +474,12 @@ class _PhotoLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, cfg, target, K, invK, ident_min, noise, ext_mask, *rest):
         F, S = cfg["F"], cfg["S"]
-        srcs = [_prep(t, "source frame") for t in rest[:F]]
+        srcs = list(rest[:F])             # packed (B,H,W,4), see photometric_loss
         Ts = [_prep(t, "T").reshape(-1, 4, 4) for t in rest[F:2 * F]]
         dzs = [_prep(t, "disp / depth") for t in rest[2 * F:2 * F + S]]
-        target, K, invK = _prep(target, "target"), _prep(K, "K"), _prep(invK, "inv_K")
+        K, invK = _prep(K, "K"), _prep(invK, "inv_K")
         ident_min, noise, ext_mask = _prep(ident_min, "identity loss"), _prep(noise, "noise"), _prep(ext_mask, "mask")
-        B, Ci, H, W = target.shape
-        if Ci != 3:
-            raise _lib.MovedepthHipError("photometric_loss: images must have 3 channels (got %d)" % Ci)
+        B, H, W, _ = target.shape
         dev, f32 = target.device, torch.float32
         for z in dzs:
             if not cfg["is_disp"] and z.numel() != B * H * W:
@@ -452,7 +488,7 @@ class _PhotoLoss(torch.autograd.Function):
             raise RuntimeError("noise must have S*B*H*W = %d elements (one draw per scale, trainer.py:698)" % (S * B * H * W))
         d = _lib.PhotoDesc()
         _fill_desc(d, cfg, target, srcs, Ts, K, invK, dzs, ident_min, noise, ext_mask)
-        warped = torch.empty(S, F, B, 3, H, W, device=dev, dtype=f32)
+        warped = torch.empty(S, F, B, H, W, 4, device=dev, dtype=f32)   # packed; handed out as (B,3,H,W) views
         pix = torch.empty(S, F, B, H, W, 2, device=dev, dtype=f32) if cfg["want_pix"] else None
         oob = torch.empty(F, B, H, W, device=dev, dtype=torch.uint8) if cfg["want_oob"] else None
         depth_out = torch.empty(S, B, 1, H, W, device=dev, dtype=f32) if cfg["is_disp"] else None
@@ -497,7 +533,7 @@ class _PhotoLoss(torch.autograd.Function):
         target, K, invK, warped, sel, loss2 = saved[:6]
         srcs, Ts, dzs = saved[6:6 + F], saved[6 + F:6 + 2 * F], saved[6 + 2 * F:6 + 2 * F + S]
         mask = saved[6 + 2 * F + S] if ctx.has_mask else None
-        B, _, H, W = target.shape
+        B, H, W, _ = target.shape
         d = _lib.PhotoDesc()
         _fill_desc(d, cfg, target, srcs, Ts, K, invK, dzs, None, None, None)
         gl = [None if g is None else g.reshape(1).contiguous().float() for g in grads[:S]]
@@ -529,7 +565,8 @@ def photometric_loss(target, srcs, Ts, K, invK, depths, is_disp=False, min_depth
     """generate_images_pred + compute_losses' photometric part for one group of losses, in one launch each way
     (reference trainer.py:491-532 with 675-709 [mono, every scale], 498-509 with 621-662 [MVS], 569-612 [fused depth]).
 
-    target (B,3,H,W); srcs: F source frames (B,3,H,W); Ts: F poses (B,4,4); depths: S tensors -- disparity pyramid levels
+    target (B,3,H,W) or packed (B,H,W,4) (pack_rgbx: the kernels read packed images; planar ones are packed here, so pack the
+    frames once per step when several calls share them); srcs: F source frames, likewise; Ts: F poses (B,4,4); depths: S tensors -- disparity pyramid levels
     (B,1,h_s,w_s) when is_disp (up-sampled to HxW and converted with min/max_depth inside) or depth maps (B,[1,]H,W).
     ident_min (B,1,H,W): the identity loss of identity_loss(); noise (S,B,1,H,W): the 1e-5-scaled tie-break noise.
     Returns a dict: loss (list of S scalars, differentiable w.r.t. depths and Ts), warped[s][f], pix[s][f] | None,
@@ -540,10 +577,13 @@ def photometric_loss(target, srcs, Ts, K, invK, depths, is_disp=False, min_depth
     cfg = dict(F=F, S=S, is_disp=bool(is_disp), identity=False, mvs_mode=bool(mvs_mode), no_ssim=bool(no_ssim) or ssim_w == 0,
                ssim_w=float(ssim_w), min_depth=float(min_depth), max_depth=float(max_depth), want_pix=bool(want_pix),
                want_oob=bool(want_oob), want_mask=bool(want_mask) or ext_mask is not None)
-    out = _PhotoLoss.apply(cfg, target, K, invK, ident_min, noise, ext_mask, *srcs, *Ts, *depths)
+    if not target.is_cuda:
+        raise _lib.MovedepthHipError("photometric_loss: target must be a GPU tensor (got %s): the HIP path has no CPU fallback" % target.device)
+    packed = _packed([target] + list(srcs))
+    out = _PhotoLoss.apply(cfg, packed[0], K, invK, ident_min, noise, ext_mask, *packed[1:], *Ts, *depths)
     warped, pix, oob, depth_out, mn, mask = out[S:]
     return {"loss": list(out[:S]),
-            "warped": [[warped[s, f] for f in range(F)] for s in range(S)],
+            "warped": [[packed_view(warped[s, f]) for f in range(F)] for s in range(S)],
             "pix": None if pix is None else [[pix[s, f] for f in range(F)] for s in range(S)],
             "oob": None if oob is None else [oob[f] for f in range(F)],
             "depth": None if depth_out is None else [depth_out[s] for s in range(S)],
@@ -556,9 +596,11 @@ def identity_loss(target, srcs, ssim_w=0.85, no_ssim=False):
     loss the auto-mask compares against, evaluated once per step (it does not depend on the scale) -> (B,1,H,W).  no_grad:
     its inputs are the input frames."""
     with torch.no_grad():
-        target = _prep(target, "target")
-        srcs = [_prep(t, "source frame") for t in srcs]
-        B, _, H, W = target.shape
+        if not target.is_cuda:
+            raise _lib.MovedepthHipError("identity_loss: target must be a GPU tensor (got %s)" % target.device)
+        packed = _packed([target] + list(srcs))
+        target, srcs = packed[0], packed[1:]
+        B, H, W, _ = target.shape
         cfg = dict(is_disp=False, identity=True, mvs_mode=False, no_ssim=bool(no_ssim) or ssim_w == 0, ssim_w=float(ssim_w),
                    min_depth=0.1, max_depth=100.0)
         d = _lib.PhotoDesc()

@@ -253,7 +253,8 @@ class Trainer:
         """Pass a minibatch through the networks and generate images and losses (reference trainer.py:297-442)."""
         opt = self.opt
         for key, ipt in inputs.items():
-            inputs[key] = ipt.to(self.device, non_blocking=True)
+            if torch.is_tensor(ipt):     # (private entries of an earlier call on the same dictionary are not tensors)
+                inputs[key] = ipt.to(self.device, non_blocking=True)
         outputs = {}
         if not opt.load_pose:
             outputs.update(self.predict_poses(inputs, None))
@@ -392,10 +393,9 @@ class Trainer:
         stores are outputs, not graph nodes: gradients flow through the stashed losses."""
         opt = self.opt
         K, inv_K = inputs[("K", 0)], inputs[("inv_K", 0)]
-        target = inputs[("color", 0, 0)]
         frames = opt.frame_ids[1:]
-        srcs = [inputs[("color", f, 0)] for f in frames]
-        B, _, H, W = target.shape
+        target, srcs = self._packed_frames(inputs)
+        B, _, H, W = inputs[("color", 0, 0)].shape
         common = dict(min_depth=opt.min_depth, max_depth=opt.max_depth, ssim_w=opt.ssim_lw, no_ssim=opt.no_ssim)
         if is_mvs:
             ext = None
@@ -427,6 +427,16 @@ class Trainer:
                 outputs[("color", f, scale)] = res["warped"][si][i]
                 outputs[("color_identity", f, scale)] = inputs[("color", f, 0)]
         outputs[("_photo", "mono")] = res
+
+    def _packed_frames(self, inputs):
+        """The step's frames in the fused kernels' image layout ((B,H,W,4) RGBx), packed once per step in one launch and kept in
+        `inputs` under a private key.  Returns (target, [source frames])."""
+        key = ("_rgbx", 0)
+        if key not in inputs or inputs[key][0] is not inputs[("color", 0, 0)]:
+            packed = ops.pack_rgbx([inputs[("color", f, 0)] for f in self.opt.frame_ids])
+            inputs[key] = (inputs[("color", 0, 0)], packed)
+        packed = inputs[key][1]
+        return packed[0], packed[1:]
 
     def compute_reprojection_loss(self, pred, target, ssim_lw=None):
         """SSIM + L1 photometric loss (reference trainer.py:535-550) -> (B,1,H,W)."""
@@ -465,12 +475,12 @@ class Trainer:
         target = inputs[("color", 0, 0)]
         if opt.fused_photometric:
             frames = opt.frame_ids[1:]
-            srcs = [inputs[("color", f, 0)] for f in frames]
+            ptarget, srcs = self._packed_frames(inputs)
             ident = noise = None
             if opt.mask_mvs_auto:
-                ident = ops.identity_loss(target, srcs, 0.0, True)
+                ident = ops.identity_loss(ptarget, srcs, 0.0, True)
                 noise = self._automask_noise((target.shape[0], 1) + tuple(target.shape[2:]), 1)
-            res = ops.photometric_loss(target, srcs, [outputs[("cam_T_cam", 0, f)].detach() for f in frames], K, inv_K,
+            res = ops.photometric_loss(ptarget, srcs, [outputs[("cam_T_cam", 0, f)].detach() for f in frames], K, inv_K,
                                        [depth_fuse], min_depth=opt.min_depth, max_depth=opt.max_depth, ssim_w=0.0, no_ssim=True,
                                        ident_min=ident, noise=noise, want_mask=True)
             for i, f in enumerate(frames):

@@ -38,7 +38,10 @@ def main():
     B, H, W = a.B, a.H, a.W
     torch.manual_seed(0)
     inp = make_inputs(B, H, W, [0, -1, 1], seed=0, device="cuda")
-    target, srcs = inp[("color", 0, 0)], [inp[("color", -1, 0)], inp[("color", 1, 0)]]
+    planar = [inp[("color", 0, 0)], inp[("color", -1, 0)], inp[("color", 1, 0)]]
+    packed = ops.pack_rgbx(planar)                    # what the trainer does once per step
+    target, srcs = packed[0], packed[1:]
+    ptarget, psrcs = planar[0], planar[1:]
     K, invK = inp[("K", 0)], inp[("inv_K", 0)]
     Ts = [transformation_from_parameters(0.01 * torch.randn(B, 1, 3, device="cuda"), 0.05 * torch.randn(B, 1, 3, device="cuda"),
                                          invert=(i == 0)).requires_grad_(True) for i in range(2)]
@@ -59,11 +62,11 @@ def main():
             out["loss"][0].backward()
 
     def unfused_mono(bwd):
-        ident = torch.cat([ops.reprojection_loss(s, target) for s in srcs], 1)
+        ident = torch.cat([ops.reprojection_loss(s, ptarget) for s in psrcs], 1)
         tot = 0
         for s in range(4):
             d = ops.disp_to_depth_up(disps[s], H, W, 0.1, 100.0)
-            rl = torch.cat([ops.reprojection_loss(ops.warp_border(srcs[f], d, K, invK, Ts[f], want_pix=True)[0], target) for f in range(2)], 1)
+            rl = torch.cat([ops.reprojection_loss(ops.warp_border(psrcs[f], d, K, invK, Ts[f], want_pix=True)[0], ptarget) for f in range(2)], 1)
             tot = tot + ops.masked_min_loss(rl, ident, noise[s])[0]
         if bwd:
             tot.backward()
