@@ -5,7 +5,7 @@ forward, against fixtures produced by the REFERENCE's own Trainer.process_batch 
 The sub-model weights are rebuilt from a seed on the CPU (tools/step_fixture.py) and proven equal to the generator's by
 per-tensor checksums.  Tolerances: north_star's 1e-4 relative for every loss and for the continuous maps (norm-wise);
 quantities behind a hard decision (the arg-max of a near-uniform probability volume in `localmax`, the auto-mask's
-arg-min, threshold masks) are compared with a small allowance of flipped pixels, stated per assert (measured: none flip).
+arg-min, threshold masks) must agree at EVERY pixel of the committed fixtures (zero flips asserted).
 Gradients: 1e-4, widened only where the fixture shows the reference's own float32-vs-float64 distance to be larger.
 """
 import os
@@ -139,7 +139,7 @@ def test_process_batch_matches_reference(tag):
     assert report["color_m1_0"] <= 1e-4
     # maps downstream of localmax's arg-max over a near-uniform probability volume (untrained weights: neighbouring
     # bins differ by ~1e-3 relative): a pixel whose arg-max moves to the neighbouring bin changes its depth by a few
-    # per cent; allow 0.2 % of such pixels (none observed), the rest must agree to 1e-4
+    # per cent; none does on the committed fixtures (asserted), every pixel agrees to 1e-4
     for key in ("depth_mvs", "masked_depth", "fused_depth", "mvs_reprojection_loss"):
         r, frac = _flip_tolerant(host(outputs[key]), g["out:" + key], key, rtol=1e-4, max_flip_frac=0.0)
         report[key], report[key + ":flips"] = r, frac
