@@ -81,7 +81,9 @@ int mm_blocks(int total) {
 }
 
 // ------------------------------------------------------------------ smoothness
-constexpr int SM_BLK = 64;  // blocks per sample for the pixel passes
+// blocks per sample (and level) for the pixel passes.  256: with 64 the full-resolution level -- 122,880 pixels per sample, four
+// exp() edge weights per pixel in the backward -- ran on 384 workgroups (45 us for the four levels' backward)
+constexpr int SM_BLK = 256;
 constexpr int SM_MAXS = MD_PHOTO_MAX_SCALES;
 
 // All pyramid levels of one compute_losses call in one launch per pass (grid z = level): 3 + 3 launches per step instead of
@@ -185,8 +187,7 @@ __global__ __launch_bounds__(256) void smooth_bwd_finish_kernel(const SmoothArgs
     const float *ws = wsall + lv * sm_ws_floats(B);
     float *d_disp = a.d_disp[lv];
     const float dn = sample_mean(ws, B, b, hw, red) + 1e-7f;
-    float dot = 0.f;
-    for (int k = 0; k < SM_BLK; ++k) dot += ws[B + (size_t)B * SM_BLK * 2 + (size_t)b * SM_BLK + k];
+    const float dot = block_sum(threadIdx.x < SM_BLK ? ws[B + (size_t)B * SM_BLK * 2 + (size_t)b * SM_BLK + threadIdx.x] : 0.f, red);
     const float corr = dot / (dn * dn) / (float)hw;
     for (int p = blockIdx.x * 256 + threadIdx.x; p < hw; p += SM_BLK * 256)
         d_disp[(size_t)b * hw + p] = d_disp[(size_t)b * hw + p] / dn - corr;

@@ -634,17 +634,41 @@ __global__ __launch_bounds__(256) void up_adjoint_kernel(const md_photo_desc a, 
         // iterations per pixel for one non-zero term
         const int n = (h == H && w == W) ? 0 : fw * (oy_hi - oy_lo + 1);
         if (n == 0) acc = g[(size_t)iy * W + ix];
+        const int side = lpp >= 64 ? 8 : (lpp >= 16 ? 4 : (lpp >= 4 ? 2 : 1));   // the pixel's lanes as a side x side grid
+        if (n > 0 && exact && side * side == lpp) {
+            // lane (sub / side, sub % side) takes window rows sub_y + side * j and columns sub_x + side * i: no division by the
+            // window width per element, and a row's / column's weight is formed once (the index arithmetic of the flat loop
+            // below was 70 instructions per element: 28 us of the kernel's 42)
+            const int sub_y = sub / side, sub_x = sub % side;
+            const int fh = oy_hi - oy_lo + 1;
+            for (int oy = oy_lo + sub_y; oy < oy_lo + fh; oy += side) {
+                int y0, y1; float ly;
+                interp_idx_s(oy, h, sy, y0, y1, ly);
+                const float wy = (y0 == iy ? 1.f - ly : 0.f) + (y1 == iy ? ly : 0.f);
+                if (wy == 0.f) continue;   // (uniform over most of the wave: whole window rows fall outside the pixel's support)
+                for (int ox = ox_lo + sub_x; ox < ox_lo + fw; ox += side) {
+                    const float gv = g[(size_t)oy * W + ox];
+                    int x0, x1; float lx;
+                    interp_idx_s(ox, w, sx, x0, x1, lx);
+                    const float wx = (x0 == ix ? 1.f - lx : 0.f) + (x1 == ix ? lx : 0.f);
+                    if (wx != 0.f) acc += gv * wy * wx;
+                }
+            }
+        } else {
+        // (non-integer ratios) no early `continue`: the loads stay unconditional
+#pragma unroll 2
         for (int k = sub; k < n; k += lpp) {
             const int oy = oy_lo + k / fw, ox = ox_lo + k % fw;
+            const float gv = g[(size_t)oy * W + ox];
             int y0, y1; float ly;
             interp_idx_s(oy, h, sy, y0, y1, ly);
             const float wy = (y0 == iy ? 1.f - ly : 0.f) + (y1 == iy ? ly : 0.f);
-            if (wy == 0.f) continue;
             int x0, x1; float lx;
             interp_idx_s(ox, w, sx, x0, x1, lx);
             const float wx = (x0 == ix ? 1.f - lx : 0.f) + (x1 == ix ? lx : 0.f);
-            if (wx == 0.f) continue;
-            acc += g[(size_t)oy * W + ox] * wy * wx;
+            const float wgt = wy * wx;
+            if (wgt != 0.f) acc += gv * wy * wx;
+        }
         }
     }
     for (int o = 1; o < lpp; o <<= 1) acc += __shfl_xor(acc, o, 64);  // fixed tree: deterministic

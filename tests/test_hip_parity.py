@@ -53,7 +53,11 @@ def test_schedule_golden(ops, ty):
     g = load_golden("schedule")
     D, f = int(g["ndepth"]), float(g["scale_fac"])
     assert_close(host(ops.schedule_depth_range(dev(g["prior"]), D, f, None, ty)), g["v2_" + ty], rtol=1e-5)
-    assert_close(host(ops.schedule_depth_range(dev(g["prior"]), D, f, dev(g["z_trans"]), ty)), g["zv2_" + ty], rtol=1e-5)
+    full = ops.schedule_depth_range(dev(g["prior"]), D, f, dev(g["z_trans"]), ty)
+    assert_close(host(full), g["zv2_" + ty], rtol=1e-5)
+    # the trainer asks for the first / last planes only, as a two-bin schedule (interval positions 0 and 1 whatever D): bit-equal
+    ends = ops.schedule_depth_range(dev(g["prior"]), 2, f, dev(g["z_trans"]), ty)
+    assert torch.equal(ends[:, 0], full[:, 0]) and torch.equal(ends[:, 1], full[:, -1])
 
 
 # ------------------------------------------------------------------ cost volume
