@@ -48,8 +48,8 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(const float *__restrict__
                                                        const float *__restrict__ depth, const float *__restrict__ K,
                                                        const float *__restrict__ invK, const float *__restrict__ T,
                                                        int Ci, int H, int W, float *__restrict__ d_depth,
-                                                       float *__restrict__ ws) {
-    __shared__ float red[4][12];
+                                                       double *__restrict__ ws) {
+    __shared__ double red[4][12];
     const int b = blockIdx.z;
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     const bool valid = x < W && y < H;
@@ -92,9 +92,10 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(const float *__restrict__
             for (int j = 0; j < 4; ++j) dP[i * 4 + j] = dc[i] * Xh[j];
     }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // float inside 16-lane rows (neighbouring pixels), double above: the terms cancel across image regions (see photo.hip)
 #pragma unroll
     for (int i = 0; i < 12; ++i) {
-        const float s = md_wave_sum(dP[i]);
+        const double s = md_wave_sum_dpp_f16_d(dP[i]);
         if (lane == 0) red[wave][i] = s;
     }
     __syncthreads();
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(const float *__restrict__
 
 // Deterministic second stage: sum the per-block dP partials of a sample, then dT = K[:3,:]^T dP.
 // The partials cancel heavily (sum |terms| >> |sum|), so this stage accumulates in fp64.
-__global__ __launch_bounds__(256) void warp_bwd_finish_kernel(const float *__restrict__ ws, const float *__restrict__ K,
+__global__ __launch_bounds__(256) void warp_bwd_finish_kernel(const double *__restrict__ ws, const float *__restrict__ K,
                                                               int nblk, float *__restrict__ d_T) {
     __shared__ double red[4][12];
     __shared__ double dP[12];
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(256) void warp_bwd_finish_kernel(const float *__res
     for (int i = 0; i < 12; ++i) acc[i] = 0.0;
     for (int k = threadIdx.x; k < nblk; k += 256)
 #pragma unroll
-        for (int i = 0; i < 12; ++i) acc[i] += (double)ws[((size_t)b * nblk + k) * 12 + i];
+        for (int i = 0; i < 12; ++i) acc[i] += ws[((size_t)b * nblk + k) * 12 + i];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
     for (int i = 0; i < 12; ++i) {
@@ -221,7 +222,7 @@ extern "C" int md_warp_fwd(const float *img, const float *depth, const float *K,
 }
 
 extern "C" size_t md_warp_bwd_ws_bytes(int B, int H, int W) {
-    return sizeof(float) * 12 * (size_t)B * md_cdiv(W, 64) * md_cdiv(H, 4);
+    return sizeof(double) * 12 * (size_t)B * md_cdiv(W, 64) * md_cdiv(H, 4);
 }
 
 extern "C" int md_warp_bwd(const float *gout, const float *img, const float *depth, const float *K, const float *invK,
@@ -232,9 +233,9 @@ extern "C" int md_warp_bwd(const float *gout, const float *img, const float *dep
     MD_REQUIRE(gout && img && depth && K && invK && T && d_depth && d_T && ws, "md_warp_bwd: null tensor");
     dim3 grid(md_cdiv(W, 64), md_cdiv(H, 4), B);
     hipLaunchKernelGGL(warp_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, gout, img, depth, K, invK, T, Ci, H, W,
-                       d_depth, (float *)ws);
+                       d_depth, (double *)ws);
     MD_CHECK_LAUNCH("md_warp_bwd");
-    hipLaunchKernelGGL(warp_bwd_finish_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, (const float *)ws, K,
+    hipLaunchKernelGGL(warp_bwd_finish_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, (const double *)ws, K,
                        (int)(grid.x * grid.y), d_T);
     MD_CHECK_LAUNCH("md_warp_bwd(finish)");
     return MD_OK;
