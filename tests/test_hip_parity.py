@@ -1046,7 +1046,9 @@ def test_reg3d_fused_bn_paths_agree(ops):
 # ------------------------------------------------------------------ cost volume with 2-byte feature maps / volume
 @pytest.mark.parametrize("dtype,tol_rounded,tol_exact", [(torch.bfloat16, 1.5e-3, 4e-3), (torch.float16, 2e-4, 5e-4)])
 @pytest.mark.parametrize("fused,layout", [(False, "bgd"), (True, "bgd"), (True, "ndhwc")])
-@pytest.mark.parametrize("case", [dict(B=2, C=32, G=16, h=24, w=40, D=12), dict(B=1, C=32, G=16, h=48, w=160, D=16)])
+@pytest.mark.parametrize("case", [dict(B=2, C=32, G=16, h=24, w=40, D=12), dict(B=1, C=32, G=16, h=48, w=160, D=16),
+                                  dict(B=1, C=32, G=16, h=24, w=40, D=13),   # odd slice: the unpaired tail of the 16-byte store path
+                                  dict(B=1, C=16, G=8, h=24, w=40, D=11)])   # two lanes per pixel
 def test_costvol_half_io_vs_oracle(ops, oracle_lib, case, fused, layout, dtype, tol_rounded, tol_exact):
     """BASELINE configs 4 / 5 precision: bf16 or fp16 feature maps and volume, fp32 arithmetic in between.  The oracle gets
     the *rounded* features as floats; the kernel's output must equal the oracle's fp32 volume rounded to the format (a
