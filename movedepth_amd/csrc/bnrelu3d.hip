@@ -61,7 +61,16 @@ __global__ __launch_bounds__(256) void bn_finish_kernel(const float *__restrict_
     __shared__ double sh[256];
     const int o = threadIdx.x % KC, seg = threadIdx.x / KC, nseg = 256 / KC;
     double s = 0.0;
-    for (int i = seg; i < nblk; i += nseg) s += (double)partial[(size_t)i * KC + o];
+    int i = seg;
+    // eight loads in flight per thread: one dependent load per iteration made this single-block kernel 32 us long (2048 partials)
+    for (; i + 7 * nseg < nblk; i += 8 * nseg) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = partial[(size_t)(i + u * nseg) * KC + o];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += (double)v[u];
+    }
+    for (; i < nblk; i += nseg) s += (double)partial[(size_t)i * KC + o];
     sh[threadIdx.x] = s;
     __syncthreads();
     if (seg == 0) {
