@@ -816,7 +816,7 @@ int launch_cl(const CvPtrs &q, CvDims dm, hipStream_t stream) {
     dm.stats = md_stats_buffer();
     dm.wflags = nullptr;
     dm.wmode = 0;
-    // Wild-pose fallback, backward only (see cv_mode_kernel): a one-wave-per-sample pre-pass flags the samples whose taps would
+    // Wild-pose fallback, backward only (see cv_mode_kernel): a one-workgroup-per-sample pre-pass flags the samples whose taps would
     // thrash the small window; this file's kernel skips them and the first-generation backward takes them in a second launch.
     // With sane poses no sample is flagged and the second launch's workgroups exit at once (~5 us).  MD_COSTVOL_WILD=0 switches
     // the mechanism off, =1 flags every sample.
@@ -828,7 +828,7 @@ int launch_cl(const CvPtrs &q, CvDims dm, hipStream_t stream) {
         MD_CHECK_HIP(hipGetSymbolAddress((void **)&flags, HIP_SYMBOL(g_cv_flags)));
         flags += (size_t)(slot_ctr.fetch_add(1) % CV_FLAG_SLOTS) * CV_FLAG_MAXB;
         // the backward's tile and window: 16 (or 32) x NW pixels + cl_bwd_hx x CL_BWD_HY cells
-        hipLaunchKernelGGL(cv_mode_kernel, dim3(dm.B), dim3(64), 0, stream, q.K, q.invK, q.pose, q.hyp, q.prior, q.ztrans, dm, TW, NW,
+        hipLaunchKernelGGL(cv_mode_kernel, dim3(dm.B), dim3(256), 0, stream, q.K, q.invK, q.pose, q.hyp, q.prior, q.ztrans, dm, TW, NW,
                            TW + cl_bwd_hx(NW), NW + CL_BWD_HY, wild_env == 1 ? 1 : 0, flags);
         MD_CHECK_LAUNCH("md_costvol_bwd (pose pre-pass)");
         dm.wflags = flags;
@@ -1047,7 +1047,12 @@ extern "C" int MD_CV_NAME(md_costvol_bwd)(const abi_io_t *gout_, long long g_sb,
     dm.B = B; dm.C = C; dm.G = G; dm.h = h; dm.w = w; dm.D = D;
     dm.sb = g_sb; dm.sd = g_sd; dm.sg = g_sg; dm.sp = g_sp;
     const size_t bytes = sizeof(float) * (size_t)B * C * h * w;
-    MD_CHECK_HIP(hipMemsetAsync(d_src, 0, bytes, (hipStream_t)stream));
-    MD_CHECK_HIP(hipMemsetAsync(d_ref, 0, bytes, (hipStream_t)stream));
+    // one fill when the caller allocated the two gradients back to back (ops.py does): each fill is a 5 us launch
+    if ((char *)d_ref + bytes == (char *)d_src) {
+        MD_CHECK_HIP(hipMemsetAsync(d_ref, 0, 2 * bytes, (hipStream_t)stream));
+    } else {
+        MD_CHECK_HIP(hipMemsetAsync(d_src, 0, bytes, (hipStream_t)stream));
+        MD_CHECK_HIP(hipMemsetAsync(d_ref, 0, bytes, (hipStream_t)stream));
+    }
     return launch<true>(q, dm, (hipStream_t)stream);
 }

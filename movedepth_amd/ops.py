@@ -182,8 +182,9 @@ class _CostVolume(torch.autograd.Function):
         scale_fac, sched_type, G, D, layout, has_hyp, has_prior, has_z = ctx.meta
         B, C, h, w = ref.shape
         g, (sb, sd, sg, sp) = _vol_as_layout(gout.to(ctx.io), layout)  # no copy when the consumer kept the layout
-        d_ref = torch.empty(ref.shape, device=ref.device, dtype=torch.float32)   # fp32 accumulation (atomics)
-        d_src = torch.empty_like(d_ref)
+        # fp32 accumulation (atomics); one allocation, d_ref then d_src: the library zeroes them with a single fill
+        d_both = torch.empty((2,) + tuple(ref.shape), device=ref.device, dtype=torch.float32)
+        d_ref, d_src = d_both[0], d_both[1]
         _timed_call("md_costvol_bwd" + ctx.sfx, _p(g), sb, sd, sg, sp, _p(ref), _p(src), _p(K), _p(invK), _p(pose),
                     _p(hyp if has_hyp else None), _p(prior if has_prior else None), _p(ztrans if has_z else None),
                     scale_fac, sched_type, B, C, G, h, w, D, _p(d_ref), _p(d_src), _stream())

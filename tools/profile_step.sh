@@ -61,4 +61,13 @@ with open("$OUT", "w") as f:
     f.write("# %-70s %7.2f\n" % ("other", other))
     f.write("# %-70s %7.2f\n" % ("sum", other + sum(acc.values())))
 print(open("$OUT").read()[-2500:])
+# neighbourhood of the plane-sweep launches inside one step (what runs just before matters: dirty lines still being written back)
+print("# ---- plane-sweep launches of the last timed step: two predecessors, gap, own duration")
+last = [r for r in rows if marks[-2] <= int(r["Start_Timestamp"]) < marks[-1]]
+for i, r in enumerate(last):
+    if "cl_fwd_kernel" in r["Kernel_Name"] or "cl_bwd_kernel" in r["Kernel_Name"]:
+        for q in last[max(i - 2, 0):i + 1]:
+            print("#   %-90s %8.1f us  (starts %8.1f us after the previous kernel ended)" % (q["Kernel_Name"][:90], (int(q["End_Timestamp"]) - int(q["Start_Timestamp"])) / 1e3,
+                  (int(q["Start_Timestamp"]) - int(last[last.index(q) - 1]["End_Timestamp"])) / 1e3 if last.index(q) else 0.0))
+        print("#")
 PY
