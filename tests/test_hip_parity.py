@@ -261,6 +261,33 @@ def test_costvol_wide_coordinates_white_noise(ops, oracle_lib, w, h):
     assert_close(host(s.grad), exp_dsrc, what="d_src")
 
 
+@pytest.mark.parametrize("C", [32, 16, 64])
+def test_costvol_near_prior_carried_sums_vs_oracle(ops, oracle_lib, C):
+    """A near scene (prior 0.4-1.2 m, translation 5 cm): the sample position crosses a source cell every few hypotheses, to
+    the right for one sample and to the left for the other (a third moves up / down / diagonally).  The backward keeps the
+    pending sums of the tap column that the next cell still covers instead of flushing them (csrc/costvol_cl.inc flush_col);
+    white-noise features and gradients so that a sum carried into the wrong column shows.  1, 2 and 4 channels per group."""
+    rng = np.random.default_rng(91)
+    B, G, h, w, D = 3, 16, 24, 80, 48
+    ref = rng.standard_normal((B, C, h, w)).astype(np.float32)
+    src = rng.standard_normal((B, C, h, w)).astype(np.float32)
+    K, invK = kitti_K(h, w, B)
+    prior = (0.4 + 0.8 * smooth_field(rng, (B, 1, h, w), 6, 0, 1)).astype(np.float32)
+    pose = np.tile(np.eye(4, dtype=np.float32), (B, 1, 1))
+    pose[0, 0, 3], pose[1, 0, 3] = 0.05, -0.05
+    pose[2, 0, 3], pose[2, 1, 3], pose[2, 2, 3] = 0.02, 0.03, 0.02
+    hyp = oracle_lib.schedule_depth_range(prior, D, 0.3, None, "inverse")
+    gout = rng.standard_normal((B, D, G, h, w)).astype(np.float32)
+    exp = oracle_lib.costvol_grouped(ref, src, K, invK, hyp, pose, G)
+    exp_dref, exp_dsrc = oracle_lib.costvol_grouped_bwd(gout, ref, src, K, invK, hyp, pose)
+    r, s = dev(ref, True), dev(src, True)
+    vol = ops.costvol_grouped(r, s, dev(K), dev(invK), dev(pose), G, prior=dev(prior), ndepth=D, scale_fac=0.3, layout="ndhwc")
+    assert_close(host(vol), exp, what="volume")
+    vol.backward(dev(gout))
+    assert_close(host(r.grad), exp_dref, what="d_ref")
+    assert_close(host(s.grad), exp_dsrc, what="d_src")
+
+
 def test_costvol_wild_poses_backward_fallback_vs_oracle(ops, oracle_lib):
     """Poses of an untrained pose network (axis-angle ~ N(0, 0.3^2) rad, translation ~ N(0, 2^2)): md_costvol_bwd's pre-pass
     flags the samples whose taps would thrash the channels-last kernel's window and hands them to the first-generation backward

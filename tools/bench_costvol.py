@@ -61,6 +61,7 @@ def main():
         prior = torch.full((B, 1, h, w), float(os.environ.get("PRIOR_CONST", "8.0")), device=dev)
     pose = torch.eye(4, device=dev).repeat(B, 1, 1)
     pose[:, 0, 3], pose[:, 2, 3] = float(os.environ.get("POSE_TX", "0.05")), float(os.environ.get("POSE_TZ", "0.03"))
+    pose[:, 1, 3] = float(os.environ.get("POSE_TY", "0.0"))
     if os.environ.get("POSE_ROT"):   # "wild" poses of an untrained pose network: axis-angle ~ N(0, rot^2), translation ~ N(0, trans^2)
         from movedepth_amd.layers import transformation_from_parameters
         gen = torch.Generator(device=dev).manual_seed(7)
