@@ -169,6 +169,12 @@ def main():
     ap.add_argument("--trainer_args", default="", help="extra movedepth_amd options, e.g. '--hip_prob_conv 0' for an A/B")
     ap.add_argument("--epoch", type=int, default=0, help="trainer.epoch during the run (> ztrans_start_epc: velocity-guided bins)")
     a = ap.parse_args()
+    # stdout carries exactly one JSON line.  The convolution libraries write diagnostics to file descriptor 1 from C++ (CK's
+    # "GridwiseOp: Problemsize descriptor dimension check failure" under fp16 autocast): point fd 1 at stderr for the run and
+    # keep the real stdout for the line.
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -332,7 +338,7 @@ def main():
         ctypes.CDLL(None).fflush(None)
         if opt.amp != "none":
             sys.stdout.write("\n")
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=json_out, flush=True)
     if dist.is_available() and dist.is_initialized():
         dist.destroy_process_group()
 

@@ -67,7 +67,10 @@ int md_costvol_fwd(const float *ref, const float *src, const float *K, const flo
                    long long out_sg, long long out_sp, md_stream_t stream);
 
 /* Autograd of md_costvol_fwd w.r.t. ref and src (the sampling grid is under no_grad, layers.py:784).
- * gout addressed with the same four strides; d_ref, d_src [B,C,h,w] are overwritten. */
+ * gout addressed with the same four strides; d_ref, d_src [B,C,h,w] are overwritten (zeroed, then accumulated with
+ * atomics: one fill instead of two when d_src == d_ref + B*C*h*w).  Samples whose poses would scatter a tile's taps
+ * over more source cells than the kernel's window holds (an untrained pose network) are taken by a second launch of a
+ * scatter kernel, chosen per sample by a pose pre-pass on the device (MD_COSTVOL_WILD=0: off). */
 int md_costvol_bwd(const float *gout, long long g_sb, long long g_sd, long long g_sg, long long g_sp, const float *ref,
                    const float *src, const float *K, const float *invK, const float *pose, const float *hyp,
                    const float *prior, const float *ztrans, float scale_fac, int sched_type, int B, int C, int G,
