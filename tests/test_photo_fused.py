@@ -116,7 +116,7 @@ def test_mono_all_scales_vs_oracle(ops, oracle_lib, B, H, W, F, S):
         assert flips <= (4 if H * W > 50000 else 0), "auto-mask differs at %d pixels" % flips
         share = np.bincount(exp["reproj"].argmin(1).ravel(), minlength=F) / exp["mn"].size
         assert share.min() > 0.03 and 0.02 < exp["mask"].mean() < 0.98, (share, exp["mask"].mean())   # every branch exercised
-        assert abs(float(out["loss"][s]) - exp["loss"]) <= 1e-4 * abs(exp["loss"]), (s, float(out["loss"][s]), exp["loss"])
+        assert abs(float(out["loss"][s].detach()) - exp["loss"]) <= 1e-4 * abs(exp["loss"]), (s, float(out["loss"][s].detach()), exp["loss"])
         # a disparity pixel of level s gathers 4^s full-resolution samples: the share of pixels touched by a sample that sits on
         # a texel boundary (assert_close_knife_edge) grows with the level
         assert_close_knife_edge(host(tz[s].grad), exp["d_in"], rtol=2e-4, max_outlier_frac=2e-3 * 2 ** s, what="d_disp[%d]" % s)
