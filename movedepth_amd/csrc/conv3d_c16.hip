@@ -27,6 +27,10 @@ constexpr int NLD = (CELLS * 4 + 255) / 256;     // float4 pieces per thread per
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef MD_C16_WGRAD_GYQ
+#define MD_C16_WGRAD_GYQ 1
+#endif
+
 struct C16Dims {
     int B, D, H, W;
     int tiles_x, tiles, dslices, planes;
@@ -132,7 +136,16 @@ __global__ __launch_bounds__(256, 2) void conv3d_c16_bwd_weight_kernel(const flo
     fetch(d0);     stash(d0);
     fetch(d0 + 1);
     for (int d = d0; d < d1; ++d) {
-        float gcur = gy_load(d, 0);
+        // the plane's 16 gy operands requested up front: one group ahead is 27 MFMAs = 0.4 us, less than a trip to HBM
+        // (channels-last x only: the planar variant's wider staging leaves no registers for it)
+        constexpr bool GYQ = MD_C16_WGRAD_GYQ && !XPLANAR;
+        float gyv[GYQ ? 16 : 1], gcur = 0.f;
+        if constexpr (GYQ) {
+#pragma unroll
+            for (int g = 0; g < 16; ++g) gyv[g] = gy_load(d, g);
+        } else {
+            gcur = gy_load(d, 0);
+        }
         stash(d + 1);
         __syncthreads();
         if (d + 1 < d1) fetch(d + 2);
@@ -156,6 +169,19 @@ __global__ __launch_bounds__(256, 2) void conv3d_c16_bwd_weight_kernel(const flo
         };
         float acur[NTAP];
         a_load(0, acur);
+        if constexpr (GYQ) {
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {   // straight-line: the compiler counts the outstanding loads exactly
+            float anext[NTAP];
+            if (g + 1 < 16) a_load(g + 1, anext);
+#pragma unroll
+            for (int k = 0; k < NTAP; ++k) acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(acur[k], gyv[g], acc[k], 0, 0, 0);
+            if (g + 1 < 16) {
+#pragma unroll
+                for (int k = 0; k < NTAP; ++k) acur[k] = anext[k];
+            }
+        }
+        } else {
 #pragma unroll 1
         for (int g = 0; g < 16; ++g) {
             const float gnext = gy_load(d, (g + 1) & 15);  // one group ahead (the wrap-around load is discarded)
@@ -166,6 +192,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_c16_bwd_weight_kernel(const flo
 #pragma unroll
             for (int k = 0; k < NTAP; ++k) acur[k] = anext[k];
             gcur = gnext;
+        }
         }
         __syncthreads();  // slot (d+2)%3 == (d-1)%3 is rewritten at the top of the next step
     }
