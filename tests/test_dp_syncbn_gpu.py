@@ -133,15 +133,24 @@ def _big_batch():
 
 
 def test_default_ddp_path_with_synchronised_batchnorm_equals_the_big_batch_step():
-    world, port = 2, _free_port()
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    res = sorted([q.get(timeout=900) for _ in range(world)], key=lambda x: x[0])
-    for p in procs:
-        p.join(timeout=120)
+    world = 2
+    # Two attempts at the RENDEZVOUS only: a worker that dies of an infrastructure error (port taken between _free_port() and the
+    # bind, a stale process group) is started again once and its traceback printed; every comparison below runs on whatever the
+    # ranks return, without retry.
+    for attempt in range(2):
+        port = _free_port()
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        res = sorted([q.get(timeout=900) for _ in range(world)], key=lambda x: x[0])
+        for p in procs:
+            p.join(timeout=120)
+        errs = [r[10] for r in res if r[10] is not None]
+        if not errs or attempt == 1 or any("AssertionError" in e for e in errs):
+            break
+        print("rank launch failed, retrying once:\n" + "\n".join(errs))
     for r in res:
         assert r[10] is None, r[10]
     (_, ga, bna, wa, ca, calls_a, nb, nsync, nplain, host_a, _), (_, gb, bnb, wb, cb, calls_b, _, _, _, host_b, _) = res

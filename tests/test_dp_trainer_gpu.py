@@ -96,15 +96,24 @@ def _worker(rank, world, port, q):
 
 
 def test_trainer_two_ranks_gradient_mean_and_weight_sync():
-    world, port = 2, _free_port()
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    res = sorted([q.get(timeout=600) for _ in range(world)], key=lambda x: x[0])
-    for p in procs:
-        p.join(timeout=120)
+    world = 2
+    # Two attempts at the RENDEZVOUS only: a worker that dies of an infrastructure error (port taken between _free_port() and the
+    # bind, a stale process group) is started again once and its traceback printed; every comparison below runs on whatever the
+    # ranks return, without retry.
+    for attempt in range(2):
+        port = _free_port()
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        res = sorted([q.get(timeout=600) for _ in range(world)], key=lambda x: x[0])
+        for p in procs:
+            p.join(timeout=120)
+        errs = [r[7] for r in res if r[7] is not None]
+        if not errs or attempt == 1 or any("AssertionError" in e for e in errs):
+            break
+        print("rank launch failed, retrying once:\n" + "\n".join(errs))
     for r in res:
         assert r[7] is None, r[7]
     (_, w0a, ma, ga, w1a, na, nba, _), (_, w0b, mb, gb, w1b, nb, nbb, _) = res
