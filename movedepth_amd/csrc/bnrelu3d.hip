@@ -16,7 +16,10 @@
 
 namespace {
 
-constexpr int NBLK = 1024;  // partial sums per launch; channels C = 4*QN with QN in {4, 8, 16}
+#ifndef MD_BN_NBLK
+#define MD_BN_NBLK 1024
+#endif
+constexpr int NBLK = MD_BN_NBLK;  // partial sums per launch; channels C = 4*QN with QN in {4, 8, 16}
 
 __device__ __forceinline__ float4 f4_add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 
