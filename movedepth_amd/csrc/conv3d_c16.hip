@@ -27,6 +27,12 @@ constexpr int NLD = (CELLS * 4 + 255) / 256;     // float4 pieces per thread per
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef MD_C16_FWD_UNROLL
+#define MD_C16_FWD_UNROLL 1      // group loop straight-line: the next group's LDS reads overlap the previous group's stores
+#endif
+#ifndef MD_C16_FWD_VEC_STORE
+#define MD_C16_FWD_VEC_STORE 1   // channels-last output: D[n][voxel] mapping, one 16-byte store per lane (0: four dword stores)
+#endif
 #ifndef MD_C16_WGRAD_GYQ
 #define MD_C16_WGRAD_GYQ 1
 #endif
@@ -282,7 +288,11 @@ __global__ __launch_bounds__(256, 2) void conv3d_c16_fwd_kernel(const float *__r
         const float *s0 = ring + ((d + 2) % 3) * PLANE_F;  // planes d-1, d, d+1
         const float *s1 = ring + (d % 3) * PLANE_F;
         const float *s2 = ring + ((d + 1) % 3) * PLANE_F;
+#if MD_C16_FWD_UNROLL
+#pragma unroll
+#else
 #pragma unroll 1
+#endif
         for (int g = 0; g < 4; ++g) {  // group = tile row 2*wave + g/2, columns (g%2)*16 .. +15
             const int row = 2 * wave + (g >> 1), col0 = (g & 1) * 16;
             const int cell = row * HW_ + col0 + n;  // this lane's voxel (n doubles as the voxel index), halo origin
@@ -303,7 +313,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_c16_fwd_kernel(const float *__r
                             a = reinterpret_cast<const float4 *>(sl)[c * 4 + kk];
                         }
                         const f32x4 w4 = wr[(kd * 3 + kh) * 3 + kw];
-                        if (OUT_PLANAR) {  // D[n][voxel]: weights as A, input as B
+                        if (OUT_PLANAR || MD_C16_FWD_VEC_STORE) {  // D[n][voxel]: weights as A, input as B
                             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[0], a.x, acc, 0, 0, 0);
                             acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[1], a.y, acc1, 0, 0, 0);
                             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[2], a.z, acc, 0, 0, 0);
@@ -325,6 +335,12 @@ __global__ __launch_bounds__(256, 2) void conv3d_c16_fwd_kernel(const float *__r
                 for (int r = 0; r < 4; ++r)
                     if (yy < dm.H && xx < dm.W)
                         outb[((size_t)(4 * kk + r) * dm.D + d) * plane + (size_t)yy * dm.W + xx] = acc[r];
+            } else if (MD_C16_FWD_VEC_STORE) {
+                // register r of lane l = out[channel 4*(l>>4) + r][voxel l&15]: four consecutive channels of one voxel = one
+                // 16-byte store, the wave's 16 voxels x 64 bytes contiguous
+                const int xx = tx0 + col0 + n;
+                if (yy < dm.H && xx < dm.W)
+                    reinterpret_cast<float4 *>(outb)[((size_t)d * plane + (size_t)yy * dm.W + xx) * 4 + kk] = make_float4(acc[0], acc[1], acc[2], acc[3]);
             } else {
                 // register r of lane l = out[voxel 4*(l>>4) + r][channel l&15]
 #pragma unroll
