@@ -136,7 +136,12 @@ __global__ __launch_bounds__(256) void sel4_kernel(const float *__restrict__ g_d
 #pragma unroll
     for (int i = 0; i < SEL_NB; ++i) {
         const int d = dbeg + i;
-        v[i] = (i < nb && d < D) ? lp[d * shw] : -INFINITY;
+        v[i] = lp[min(d, D - 1) * shw];   // unconditional (clamped) so that all the loads are in flight together
+    }
+#pragma unroll
+    for (int i = 0; i < SEL_NB; ++i) {
+        const int d = dbeg + i;
+        if (!(i < nb && d < D)) v[i] = -INFINITY;
         if (v[i] > mx) { mx = v[i]; am = d; }
     }
     sh.f[0][q][pl] = mx;
