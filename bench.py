@@ -262,9 +262,12 @@ def main():
               "lanes redoing misses %d, cell-change blocks %d (%.1f lanes each), wave-steps %d" % (
                   a.steps, _buf[0], _buf[1], _buf[2], _buf[3], _buf[4], _buf[5] / max(_buf[4], 1), _buf[6]), file=sys.stderr)
     times = ops.kernel_times_us()
-    times.update(ops.library_kernel_times_us(["md_costvol_fwd" + sfx, "md_costvol_bwd" + sfx]))
+    # the backward is two launches: the channels-last kernel and, for samples its pose pre-pass flags, the scatter kernel
+    # (an empty launch of ~5 us when nothing is flagged): both are reported
+    wild = "md_costvol_bwd_wild" + sfx
+    times.update(ops.library_kernel_times_us(["md_costvol_fwd" + sfx, "md_costvol_bwd" + sfx, wild]))
     if os.environ.get("MD_BENCH_DUMP_TIMES"):
-        for k_ in ("md_costvol_fwd" + sfx, "md_costvol_bwd" + sfx):
+        for k_ in ("md_costvol_fwd" + sfx, "md_costvol_bwd" + sfx, wild):
             print(k_, " ".join("%.0f" % t for t in times.get(k_, {}).get("all_us", [])), file=sys.stderr)
     ops.enable_library_kernel_timing(False)
 
@@ -304,7 +307,8 @@ def main():
                          "traffic": traffic, "traffic_from_profile": traffic_profile, "algorithmic_bytes_per_launch": fbytes,
                          "timing": "HIP events inside libmovedepth_hip.so around the kernel launch (md_kernel_timing_*)",
                          "avg_launch_us": kt.get("avg_us"), "min_launch_us": kt.get("min_us"), "median_launch_us": kt.get("median_us"), "launches_timed": kt.get("launches"),
-                         "bwd_avg_launch_us": times.get("md_costvol_bwd" + sfx, {}).get("avg_us")},
+                         "bwd_avg_launch_us": times.get("md_costvol_bwd" + sfx, {}).get("avg_us"),
+                         "bwd_wild_pose_launch_avg_us": times.get(wild, {}).get("avg_us")},
         }
         # the 3-D regulariser's first / last convolutions (hand-off either side of it), same live HIP-event timing:
         # 16->16 is MFMA-bound (2*27*16*16 flop per voxel against the 157.3 TF/s fp32 MFMA peak), 16->1 is HBM-bound

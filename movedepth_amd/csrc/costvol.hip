@@ -88,6 +88,9 @@ __device__ __forceinline__ void stio4(io_t *p, float4 v) {
 #endif
 constexpr bool kReferenceOpOrder = MD_COSTVOL_REFERENCE_OP_ORDER != 0;
 
+#ifndef MD_CV_WILD_SLACK
+#define MD_CV_WILD_SLACK 1.5f
+#endif
 constexpr int ITV_MAX = 256;  // hypotheses per D slice served from the LDS interval table
 
 struct CvDims {
@@ -718,6 +721,13 @@ int env_int(const char *name, int dflt) {
     return (e && *e) ? atoi(e) : dflt;
 }
 
+// Wild-pose routing: a tile counts against the channels-last backward when its estimated tap footprint exceeds the window by
+// this factor (MD_COSTVOL_WILD_SLACK overrides; see launch_cl)
+float wild_slack() {
+    static const float v = [] { const char *e = getenv("MD_COSTVOL_WILD_SLACK"); const float f = (e && *e) ? (float)atof(e) : MD_CV_WILD_SLACK; return f > 0.f ? f : MD_CV_WILD_SLACK; }();
+    return v;
+}
+
 struct CvPtrs {
     const io_t *gout, *ref, *src;
     const float *K, *invK, *pose, *hyp, *prior, *ztrans;
@@ -829,7 +839,7 @@ int launch_cl(const CvPtrs &q, CvDims dm, hipStream_t stream) {
         flags += (size_t)(slot_ctr.fetch_add(1) % CV_FLAG_SLOTS) * CV_FLAG_MAXB;
         // the backward's tile and window: 16 (or 32) x NW pixels + cl_bwd_hx x CL_BWD_HY cells
         hipLaunchKernelGGL(cv_mode_kernel, dim3(dm.B), dim3(256), 0, stream, q.K, q.invK, q.pose, q.hyp, q.prior, q.ztrans, dm, TW, NW,
-                           TW + cl_bwd_hx(NW), NW + CL_BWD_HY, wild_env == 1 ? 1 : 0, flags);
+                           wild_slack() * (float)(TW + cl_bwd_hx(NW)), wild_slack() * (float)(NW + CL_BWD_HY), wild_env == 1 ? 1 : 0, flags);
         MD_CHECK_LAUNCH("md_costvol_bwd (pose pre-pass)");
         dm.wflags = flags;
     }
