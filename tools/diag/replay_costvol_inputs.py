@@ -11,12 +11,15 @@ d = np.load(sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out
 meta = d["meta"]; D, sf, G = int(meta[0]), float(meta[1]), int(meta[2]); B, C, h, w = (int(v) for v in meta[3:7])
 dt = torch.bfloat16 if os.environ.get("DT", "bf16") == "bf16" else torch.float32
 dev = lambda a: torch.from_numpy(a).cuda()
+pose = d["pose"].copy()
+if os.environ.get("POSE_TZ"):   # what-if: another translation along the optical axis
+    pose[:, 2, 3] = float(os.environ["POSE_TZ"])
 ref = torch.randn(B, C, h, w, device="cuda").to(dt).requires_grad_(True)
 src = torch.randn(B, C, h, w, device="cuda").to(dt).requires_grad_(True)
 ops.enable_library_kernel_timing(True)
 for _ in range(6):
     ref.grad = src.grad = None
-    vol = ops.costvol_grouped(ref, src, dev(d["K"]), dev(d["invK"]), dev(d["pose"]), G, prior=dev(d["prior"]), ndepth=D, scale_fac=sf, layout="ndhwc")
+    vol = ops.costvol_grouped(ref, src, dev(d["K"]), dev(d["invK"]), dev(pose), G, prior=dev(d["prior"]), ndepth=D, scale_fac=sf, layout="ndhwc")
     vol.backward(torch.randn_like(vol))
 torch.cuda.synchronize()
 sfx = "_bf16" if dt == torch.bfloat16 else ""
