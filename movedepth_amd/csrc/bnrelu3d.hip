@@ -21,6 +21,22 @@ namespace {
 #endif
 constexpr int NBLK = MD_BN_NBLK;  // partial sums per launch; channels C = 4*QN with QN in {4, 8, 16}
 
+#ifndef MD_BN_NT
+#define MD_BN_NT 1
+// The activation / gradient streams (283 MB each at config 2's first layer, read once per launch) carry the non-temporal hint:
+// 42.0 -> 41.7 ms per training step (16 launches; bench.py on one box, base 41.91 / 42.03 against 41.62, then 41.66 / 41.70 as the
+// default).  MD_BN_NT=0: plain loads (A/B).
+#endif
+__device__ __forceinline__ float4 ldst(const float4 *p) {
+#if MD_BN_NT
+    typedef float nt4_t __attribute__((ext_vector_type(4)));
+    const nt4_t v = __builtin_nontemporal_load(reinterpret_cast<const nt4_t *>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+#else
+    return *p;
+#endif
+}
+
 __device__ __forceinline__ float4 f4_add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 
 // block-wide sum of per-thread float4 (channels 4q..4q+3 of quad q = tid % QN): result valid in threads 0..QN-1
@@ -46,7 +62,7 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float4 *__restrict_
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f), ss = s;
     // consecutive threads take consecutive 16-byte pieces; the stride keeps a thread on one channel quad
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < npieces; i += (long long)gridDim.x * 256) {
-        const float4 v = x[i];
+        const float4 v = ldst(x + i);
         s = f4_add(s, v);
         ss.x = fmaf(v.x, v.x, ss.x); ss.y = fmaf(v.y, v.y, ss.y); ss.z = fmaf(v.z, v.z, ss.z); ss.w = fmaf(v.w, v.w, ss.w);
     }
@@ -98,10 +114,10 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float4 *__restrict_
         sf[k] = beta[c] - mean[c] * sc[k];
     }
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < npieces; i += (long long)gridDim.x * 256) {
-        const float4 v = x[i];
+        const float4 v = ldst(x + i);
         float4 o = make_float4(fmaxf(fmaf(v.x, sc[0], sf[0]), 0.f), fmaxf(fmaf(v.y, sc[1], sf[1]), 0.f),
                                fmaxf(fmaf(v.z, sc[2], sf[2]), 0.f), fmaxf(fmaf(v.w, sc[3], sf[3]), 0.f));
-        if (res) o = f4_add(o, res[i]);
+        if (res) o = f4_add(o, ldst(res + i));
         y[i] = o;
     }
 }
@@ -123,7 +139,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float4 *__rest
     }
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f), sx = s;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < npieces; i += (long long)gridDim.x * 256) {
-        const float4 v = x[i], g = dy[i];
+        const float4 v = ldst(x + i), g = ldst(dy + i);
         const float xv[4] = {v.x, v.y, v.z, v.w}, gv[4] = {g.x, g.y, g.z, g.w};
         float a[4], b[4];
 #pragma unroll
@@ -160,7 +176,7 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const float4 *__restrict
         m1[k] = sums[c] * inv_n; m2[k] = sums[4 * QN + c] * inv_n;
     }
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < npieces; i += (long long)gridDim.x * 256) {
-        const float4 v = x[i], g = dy[i];
+        const float4 v = ldst(x + i), g = ldst(dy + i);
         const float xv[4] = {v.x, v.y, v.z, v.w}, gv[4] = {g.x, g.y, g.z, g.w};
         float o[4];
 #pragma unroll
