@@ -27,6 +27,13 @@ constexpr int NLD = (CELLS * 4 + 255) / 256;     // float4 pieces per thread per
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef MD_C16_NT
+#define MD_C16_NT 2
+// Non-temporal hint on this file's volume loads: 1 = the weight gradient's gy stream, 2 = the staged planes of all three kernels too.
+// These kernels are MFMA-bound and do not change (510 / 500 / 611 us either way); what changes is what they leave on the die: with 2
+// the weight gradient's 566 MB of reads no longer push the data gradient's dx out of the Infinity Cache before md_costvol_bwd reads
+// it -- 72.2 -> 69.4 us for the plane-sweep backward in the training step (bench.py, three runs each over two boxes); 1: no change.
+#endif
 #ifndef MD_C16_FWD_UNROLL
 #define MD_C16_FWD_UNROLL 1      // group loop straight-line: the next group's LDS reads overlap the previous group's stores
 #endif
@@ -94,8 +101,16 @@ struct Stager {
         } else {
             const float4 *b4 = reinterpret_cast<const float4 *>(base);
 #pragma unroll
-            for (int i = 0; i < N; ++i)
+            for (int i = 0; i < N; ++i) {
+#if MD_C16_NT >= 2
+                if (in && ofs[i] >= 0) {
+                    const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(b4 + (size_t)P * pstride + ofs[i]));
+                    pre4[i] = make_float4(v[0], v[1], v[2], v[3]);
+                } else pre4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+#else
                 pre4[i] = (in && ofs[i] >= 0) ? b4[(size_t)P * pstride + ofs[i]] : make_float4(0.f, 0.f, 0.f, 0.f);
+#endif
+            }
         }
     }
     __device__ __forceinline__ void stash(float *slot) const {
@@ -131,6 +146,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_c16_bwd_weight_kernel(const flo
     // gy roles: group g of this wave = tile row 2*wave + g/8, columns (g%8)*4 .. +3; lane holds (voxel v, channel ch)
     auto gy_load = [&](int d, int g) -> float {
         const int yy = ty0 + 2 * wave + (g >> 3), xx = tx0 + (g & 7) * 4 + v;
+#if MD_C16_NT >= 1
+        return (yy < dm.H && xx < dm.W) ? __builtin_nontemporal_load(gyb + ((size_t)d * plane + (size_t)yy * dm.W + xx) * CO + ch) : 0.f;
+#endif
         return (yy < dm.H && xx < dm.W) ? gyb[((size_t)d * plane + (size_t)yy * dm.W + xx) * CO + ch] : 0.f;
     };
 
