@@ -238,7 +238,8 @@ def main():
     # plane-sweep kernels: HIP events recorded inside the library directly around the kernel launch, on the launch stream
     # (events recorded from Python around the ctypes call also time the host's launch latency whenever the GPU has run dry:
     # 77 vs 57 us for the forward inside this step); the long convolution kernels keep the Python-side events
-    ops.enable_kernel_timing(CONV_KERNELS)
+    EXTRA = [k for k in os.environ.get("MD_BENCH_EXTRA_KERNELS", "").split(",") if k]   # diagnostics: more entry points, to stderr
+    ops.enable_kernel_timing(CONV_KERNELS + EXTRA)
     ops.enable_library_kernel_timing(True)
     if os.environ.get("MD_CV_STATS"):   # diagnostics: work counters of the plane-sweep kernels over the timed steps
         from movedepth_amd import _lib as _l
@@ -262,6 +263,10 @@ def main():
               "lanes redoing misses %d, cell-change blocks %d (%.1f lanes each), wave-steps %d" % (
                   a.steps, _buf[0], _buf[1], _buf[2], _buf[3], _buf[4], _buf[5] / max(_buf[4], 1), _buf[6]), file=sys.stderr)
     times = ops.kernel_times_us()
+    for k_ in EXTRA:
+        if k_ in times:
+            print("%s: %d launches, %.1f us per step (host-side events around the call)" % (
+                k_, times[k_]["launches"], times[k_]["avg_us"] * times[k_]["launches"] / a.steps), file=sys.stderr)
     # the backward is two launches: the channels-last kernel and, for samples its pose pre-pass flags, the scatter kernel
     # (an empty launch of ~5 us when nothing is flagged): both are reported
     wild = "md_costvol_bwd_wild" + sfx
