@@ -271,6 +271,10 @@ def main():
     # (an empty launch of ~5 us when nothing is flagged): both are reported
     wild = "md_costvol_bwd_wild" + sfx
     times.update(ops.library_kernel_times_us(["md_costvol_fwd" + sfx, "md_costvol_bwd" + sfx, wild]))
+    # the convolution kernels: the same dispatch events (main kernel only -- the weight gradients' small finish kernels are
+    # separate dispatches); the Python-side figure (argument checks, workspace, finish kernel, launch gaps) is kept beside it
+    entry_us = {k_: times[k_]["avg_us"] for k_ in CONV_KERNELS if k_ in times}
+    times.update(ops.library_kernel_times_us(CONV_KERNELS))
     if os.environ.get("MD_BENCH_DUMP_TIMES"):
         for k_ in ("md_costvol_fwd" + sfx, "md_costvol_bwd" + sfx, wild):
             print(k_, " ".join("%.0f" % t for t in times.get(k_, {}).get("all_us", [])), file=sys.stderr)
@@ -315,7 +319,8 @@ def main():
                          "bwd_avg_launch_us": times.get("md_costvol_bwd" + sfx, {}).get("avg_us"),
                          "bwd_wild_pose_launch_avg_us": times.get(wild, {}).get("avg_us")},
         }
-        # the 3-D regulariser's first / last convolutions (hand-off either side of it), same live HIP-event timing:
+        # the 3-D regulariser's first / last convolutions (hand-off either side of it), same live HIP-event timing (avg_us = the
+        # kernel's own dispatch, as rocprofv3 reports it; entry_point_avg_us = events recorded from Python around the whole call):
         # 16->16 is MFMA-bound (2*27*16*16 flop per voxel against the 157.3 TF/s fp32 MFMA peak), 16->1 is HBM-bound
         # (the 16-channel volume read or written once plus the 1-channel one)
         vox = opt.batch_size * opt.num_depth_bins * h * w
@@ -324,7 +329,7 @@ def main():
             kc = times.get(name)
             if not kc:
                 continue
-            e = {"avg_us": kc["avg_us"], "launches_timed": kc["launches"]}
+            e = {"avg_us": kc["avg_us"], "launches_timed": kc["launches"], "entry_point_avg_us": entry_us.get(name)}
             if "c16" in name:
                 e["bound"], e["achieved"], e["peak"], e["unit"] = "mfma", 2 * 27 * 16 * 16 * vox / kc["avg_us"] * 1e-6, 157.3, "TFLOP/s"
             else:

@@ -724,6 +724,15 @@ bool c1_gen1() {  // MD_CONV3D_C1_GEN1=1: the first-generation kernels for every
 
 }  // namespace
 
+// Launch with the measurement hook of capi.hip: when md_kernel_timing_enable(1) is on, a start / stop event pair is tied to THIS dispatch
+// (its own begin / end timestamps, what rocprofv3's kernel trace reads) and recorded under the entry point's name; otherwise a plain launch.
+#define MD_LAUNCH_TIMED(tname, kern, grid, block, lds, s, ...)                                   \
+    do {                                                                                         \
+        hipEvent_t e0_, e1_;                                                                     \
+        md_timing_pair(tname, &e0_, &e1_);                                                       \
+        hipExtLaunchKernelGGL(kern, grid, block, lds, s, e0_, e1_, 0, __VA_ARGS__);              \
+    } while (0)
+
 extern "C" {
 
 int md_conv3d_c1_fwd(const float *x, const float *wt, long long w_stride_k, long long w_stride_c, float *y, int B, int C,
@@ -737,8 +746,8 @@ int md_conv3d_c1_fwd(const float *x, const float *wt, long long w_stride_k, long
     if (C == 16 && wl >= 0 && !c1_gen1()) {
         c1_fwd16_dims(dm);
         const dim3 grid16(dm.per_xcd ? 8 * dm.per_xcd : B * dm.tiles * dm.dslices);
-        if (wl == 0) hipLaunchKernelGGL(conv3d_c1_fwd16_kernel<0>, grid16, dim3(256), 0, s, x, wt, y, dm);
-        else hipLaunchKernelGGL(conv3d_c1_fwd16_kernel<1>, grid16, dim3(256), 0, s, x, wt, y, dm);
+        if (wl == 0) MD_LAUNCH_TIMED("md_conv3d_c1_fwd", conv3d_c1_fwd16_kernel<0>, grid16, dim3(256), 0, s, x, wt, y, dm);
+        else MD_LAUNCH_TIMED("md_conv3d_c1_fwd", conv3d_c1_fwd16_kernel<1>, grid16, dim3(256), 0, s, x, wt, y, dm);
         MD_CHECK_LAUNCH("md_conv3d_c1_fwd");
         return MD_OK;
     }
@@ -766,7 +775,7 @@ int md_conv3d_c1_bwd_data(const float *gy, const float *wt, long long w_stride_k
         dm.planes = md_cdiv(D, ds);
         dm.dslices = md_cdiv(D, dm.planes);
         const size_t lds_bytes = (size_t)(dm.planes + 2) * BD_PS * sizeof(float);
-        hipLaunchKernelGGL(conv3d_c1_bwd_data_mfma_kernel, dim3(B * dm.tiles * dm.dslices), block, lds_bytes, s, gy, wt, w_stride_k,
+        MD_LAUNCH_TIMED("md_conv3d_c1_bwd_data", conv3d_c1_bwd_data_mfma_kernel, dim3(B * dm.tiles * dm.dslices), block, lds_bytes, s, gy, wt, w_stride_k,
                            w_stride_c, dx, dm);
     }
     MD_CHECK_LAUNCH("md_conv3d_c1_bwd_data");
@@ -792,8 +801,8 @@ int md_conv3d_c1_bwd_weight(const float *x, const float *gy, float *dwt, long lo
     float *partial = (float *)ws;
     if (C == 8) hipLaunchKernelGGL(conv3d_c1_bwd_weight_kernel<2>, grid, block, 0, s, x, gy, partial, dm);
     else if (c1_gen1()) hipLaunchKernelGGL(conv3d_c1_bwd_weight_kernel<4>, grid, block, 0, s, x, gy, partial, dm);
-    else if (H % TH || W % TW) hipLaunchKernelGGL(conv3d_c1_bwd_weight_mfma_kernel<true>, grid, block, 0, s, x, gy, partial, dm);
-    else hipLaunchKernelGGL(conv3d_c1_bwd_weight_mfma_kernel<false>, grid, block, 0, s, x, gy, partial, dm);
+    else if (H % TH || W % TW) MD_LAUNCH_TIMED("md_conv3d_c1_bwd_weight", conv3d_c1_bwd_weight_mfma_kernel<true>, grid, block, 0, s, x, gy, partial, dm);
+    else MD_LAUNCH_TIMED("md_conv3d_c1_bwd_weight", conv3d_c1_bwd_weight_mfma_kernel<false>, grid, block, 0, s, x, gy, partial, dm);
     MD_CHECK_LAUNCH("md_conv3d_c1_bwd_weight");
     hipLaunchKernelGGL(conv3d_c1_bwd_weight_finish_kernel, dim3(27 * C), block, 0, s, partial, nwg, 27 * C, C, dw_stride_k,
                        dw_stride_c, dwt);

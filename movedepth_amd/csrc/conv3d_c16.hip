@@ -396,6 +396,15 @@ int c16_dims(const char *fn, int B, int Ci, int Co, int D, int H, int W, C16Dims
 
 }  // namespace
 
+// Launch with the measurement hook of capi.hip: when md_kernel_timing_enable(1) is on, a start / stop event pair is tied to THIS dispatch
+// (its own begin / end timestamps, what rocprofv3's kernel trace reads) and recorded under the entry point's name; otherwise a plain launch.
+#define MD_LAUNCH_TIMED(tname, kern, grid, block, lds, s, ...)                                   \
+    do {                                                                                         \
+        hipEvent_t e0_, e1_;                                                                     \
+        md_timing_pair(tname, &e0_, &e1_);                                                       \
+        hipExtLaunchKernelGGL(kern, grid, block, lds, s, e0_, e1_, 0, __VA_ARGS__);              \
+    } while (0)
+
 extern "C" {
 
 static int c16_launch_fwd(const char *fn, const float *in, const float *wt, long long s_n, long long s_m, long long s_k, int mirror,
@@ -407,7 +416,7 @@ static int c16_launch_fwd(const char *fn, const float *in, const float *wt, long
     if (int rc = c16_dims(fn, B, Ci, Co, D, H, W, dm)) return rc;
     const dim3 grid(B * dm.tiles * dm.dslices), block(256);
     hipStream_t s = (hipStream_t)stream;
-#define MD_C16_FWD(IP, OP) hipLaunchKernelGGL((conv3d_c16_fwd_kernel<IP, OP>), grid, block, 0, s, in, wt, s_n, s_m, s_k, mirror, out, dm)
+#define MD_C16_FWD(IP, OP) MD_LAUNCH_TIMED(fn, (conv3d_c16_fwd_kernel<IP, OP>), grid, block, 0, s, in, wt, s_n, s_m, s_k, mirror, out, dm)
     if (in_planar) { if (out_planar) MD_C16_FWD(true, true); else MD_C16_FWD(true, false); }
     else { if (out_planar) MD_C16_FWD(false, true); else MD_C16_FWD(false, false); }
 #undef MD_C16_FWD
@@ -446,8 +455,8 @@ int md_conv3d_c16_bwd_weight(const float *x, int x_planar, const float *gy, floa
     MD_REQUIRE(ws_bytes >= (size_t)nwg * NTAP * CI * CO * sizeof(float), "md_conv3d_c16_bwd_weight: workspace too small (%zu bytes)", ws_bytes);
     hipStream_t s = (hipStream_t)stream;
     float *partial = (float *)ws;
-    if (x_planar) hipLaunchKernelGGL(conv3d_c16_bwd_weight_kernel<true>, dim3(nwg), dim3(256), 0, s, x, gy, partial, dm);
-    else hipLaunchKernelGGL(conv3d_c16_bwd_weight_kernel<false>, dim3(nwg), dim3(256), 0, s, x, gy, partial, dm);
+    if (x_planar) MD_LAUNCH_TIMED("md_conv3d_c16_bwd_weight", conv3d_c16_bwd_weight_kernel<true>, dim3(nwg), dim3(256), 0, s, x, gy, partial, dm);
+    else MD_LAUNCH_TIMED("md_conv3d_c16_bwd_weight", conv3d_c16_bwd_weight_kernel<false>, dim3(nwg), dim3(256), 0, s, x, gy, partial, dm);
     MD_CHECK_LAUNCH("md_conv3d_c16_bwd_weight");
     hipLaunchKernelGGL(conv3d_c16_bwd_weight_finish_kernel, dim3(NTAP * 256 / 16), dim3(256), 0, s, partial, nwg, dw_stride_co,
                        dw_stride_ci, dw_stride_k, dwt);
