@@ -237,7 +237,8 @@ def main():
     sfx = {"none": "", "bf16": "_bf16", "fp16": "_f16"}[opt.amp]
     # plane-sweep kernels: HIP events recorded inside the library directly around the kernel launch, on the launch stream
     # (events recorded from Python around the ctypes call also time the host's launch latency whenever the GPU has run dry:
-    # 77 vs 57 us for the forward inside this step); the long convolution kernels keep the Python-side events
+    # 77 vs 57 us for the forward inside this step); the convolution kernels are read from the same in-library events below and
+    # additionally timed from Python around the whole call (entry_point_avg_us)
     EXTRA = [k for k in os.environ.get("MD_BENCH_EXTRA_KERNELS", "").split(",") if k]   # diagnostics: more entry points, to stderr
     ops.enable_kernel_timing(CONV_KERNELS + EXTRA)
     ops.enable_library_kernel_timing(True)
