@@ -148,8 +148,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_c16_bwd_weight_kernel(const flo
         const int yy = ty0 + 2 * wave + (g >> 3), xx = tx0 + (g & 7) * 4 + v;
 #if MD_C16_NT >= 1
         return (yy < dm.H && xx < dm.W) ? __builtin_nontemporal_load(gyb + ((size_t)d * plane + (size_t)yy * dm.W + xx) * CO + ch) : 0.f;
-#endif
+#else
         return (yy < dm.H && xx < dm.W) ? gyb[((size_t)d * plane + (size_t)yy * dm.W + xx) * CO + ch] : 0.f;
+#endif
     };
 
     f32x4 acc[NTAP];
