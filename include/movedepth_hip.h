@@ -60,21 +60,27 @@ int md_schedule_depth_range(const float *prior, const float *ztrans, int B, int 
  *   (strides in floats), so the volume can be laid out (B,D,G,h,w) like the reference (sp = 1), (B,G,D,h,w)
  *   as the 3-D regulariser permutes it (resnet_encoder.py:257), or channels-last (B,D,h,w,G) (sg = 1, sp = G),
  *   the layout MIOpen's fast 3-D convolutions take -- without a permute copy in any case.
+ *   feat_cl != 0: ref and src (and d_ref, d_src of the backward) are channels-last [B,h,w,C] -- what the 2-D encoder
+ *   (resnet_encoder.py:360,387 FPN4) produces when it runs in torch.channels_last -- instead of [B,C,h,w]; taken by the
+ *   channels-last-volume kernels only (sg = 1, sp = G, G = 8 or 16, C/G = 1, 2 or 4), MD_EINVAL otherwise.
  */
 int md_costvol_fwd(const float *ref, const float *src, const float *K, const float *invK, const float *pose,
                    const float *hyp, const float *prior, const float *ztrans, float scale_fac, int sched_type,
-                   int B, int C, int G, int h, int w, int D, float *out, long long out_sb, long long out_sd,
+                   int B, int C, int G, int h, int w, int D, int feat_cl, float *out, long long out_sb, long long out_sd,
                    long long out_sg, long long out_sp, md_stream_t stream);
 
 /* Autograd of md_costvol_fwd w.r.t. ref and src (the sampling grid is under no_grad, layers.py:784).
- * gout addressed with the same four strides; d_ref, d_src [B,C,h,w] are overwritten (zeroed, then accumulated with
- * atomics: one fill instead of two when d_src == d_ref + B*C*h*w).  Samples whose poses would scatter a tile's taps
- * over more source cells than the kernel's window holds (an untrained pose network) are taken by a second launch of a
- * scatter kernel, chosen per sample by a pose pre-pass on the device (MD_COSTVOL_WILD=0: off). */
+ * gout addressed with the same four strides; d_ref, d_src [B,C,h,w] ([B,h,w,C] with feat_cl) are overwritten (d_src is
+ * zeroed, then accumulated with atomics; d_ref is stored directly when every pixel's hypotheses belong to one workgroup,
+ * otherwise it takes the same route: then one fill instead of two when d_src == d_ref + B*C*h*w).  Poses that scatter a
+ * tile's taps over more source cells than the kernel's window holds (an untrained pose network): with feat_cl the kernel
+ * itself switches such hypothesis sub-slices to 16-byte gathers / atomics on L2; with planar features those samples are
+ * taken by a second launch of a scatter kernel, chosen per sample by a pose pre-pass on the device (MD_COSTVOL_WILD=0:
+ * off; the pre-pass keeps its per-launch flags in a ring of 64 device-global slots: issue these calls from ONE stream). */
 int md_costvol_bwd(const float *gout, long long g_sb, long long g_sd, long long g_sg, long long g_sp, const float *ref,
                    const float *src, const float *K, const float *invK, const float *pose, const float *hyp,
                    const float *prior, const float *ztrans, float scale_fac, int sched_type, int B, int C, int G,
-                   int h, int w, int D, float *d_ref, float *d_src, md_stream_t stream);
+                   int h, int w, int D, int feat_cl, float *d_ref, float *d_src, md_stream_t stream);
 
 /* The same two entry points with 2-byte feature maps and volume (BASELINE configs 4 and 5: bf16 / fp16 mixed precision;
  * SURVEY 8d table rows 4-5): ref, src, out and gout are bf16 (`_bf16`) or IEEE half (`_f16`) bit patterns (uint16_t
@@ -82,20 +88,20 @@ int md_costvol_bwd(const float *gout, long long g_sb, long long g_sd, long long 
  * are in elements.  Half the volume bytes (147.5 MB algorithmic per launch at config 2's shape instead of 295.1). */
 int md_costvol_fwd_bf16(const uint16_t *ref, const uint16_t *src, const float *K, const float *invK, const float *pose,
                         const float *hyp, const float *prior, const float *ztrans, float scale_fac, int sched_type, int B,
-                        int C, int G, int h, int w, int D, uint16_t *out, long long out_sb, long long out_sd,
+                        int C, int G, int h, int w, int D, int feat_cl, uint16_t *out, long long out_sb, long long out_sd,
                         long long out_sg, long long out_sp, md_stream_t stream);
 int md_costvol_bwd_bf16(const uint16_t *gout, long long g_sb, long long g_sd, long long g_sg, long long g_sp,
                         const uint16_t *ref, const uint16_t *src, const float *K, const float *invK, const float *pose,
                         const float *hyp, const float *prior, const float *ztrans, float scale_fac, int sched_type, int B,
-                        int C, int G, int h, int w, int D, float *d_ref, float *d_src, md_stream_t stream);
+                        int C, int G, int h, int w, int D, int feat_cl, float *d_ref, float *d_src, md_stream_t stream);
 int md_costvol_fwd_f16(const uint16_t *ref, const uint16_t *src, const float *K, const float *invK, const float *pose,
                        const float *hyp, const float *prior, const float *ztrans, float scale_fac, int sched_type, int B,
-                       int C, int G, int h, int w, int D, uint16_t *out, long long out_sb, long long out_sd,
+                       int C, int G, int h, int w, int D, int feat_cl, uint16_t *out, long long out_sb, long long out_sd,
                        long long out_sg, long long out_sp, md_stream_t stream);
 int md_costvol_bwd_f16(const uint16_t *gout, long long g_sb, long long g_sd, long long g_sg, long long g_sp,
                        const uint16_t *ref, const uint16_t *src, const float *K, const float *invK, const float *pose,
                        const float *hyp, const float *prior, const float *ztrans, float scale_fac, int sched_type, int B,
-                       int C, int G, int h, int w, int D, float *d_ref, float *d_src, md_stream_t stream);
+                       int C, int G, int h, int w, int D, int feat_cl, float *d_ref, float *d_src, md_stream_t stream);
 
 /* ---- frame-confidence fusion --------------------------------------------------------------
  * trainer.py:349-363: w_f = max_G softmax_G(mean_D vol_f); out = sum_f w_f vol_f / (1e-8 + sum_f w_f).

@@ -15,19 +15,21 @@ _f = ctypes.c_float
 _ll = ctypes.c_longlong
 _sz = ctypes.c_size_t
 
+# md_costvol_fwd / _bwd (and their _bf16 / _f16 twins): ..., B, C, G, h, w, D, feat_cl, ...
+_CV_FWD = [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _ll, _ll, _ll, _ll, _vp]
+_CV_BWD = [_vp, _ll, _ll, _ll, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]
+
 # name -> (restype, argtypes); must list every symbol the header declares (tests/test_cabi.py checks)
 SIGNATURES = {
     "md_last_error": (ctypes.c_char_p, []),
     "md_abi_version": (_i, []),
     "md_schedule_depth_range": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp]),
-    "md_costvol_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _i, _i, _i, _vp, _ll, _ll,
-                           _ll, _ll, _vp]),
-    "md_costvol_bwd": (_i, [_vp, _ll, _ll, _ll, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _i,
-                           _i, _i, _vp, _vp, _vp]),
-    "md_costvol_fwd_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _i, _i, _i, _vp, _ll, _ll, _ll, _ll, _vp]),
-    "md_costvol_bwd_bf16": (_i, [_vp, _ll, _ll, _ll, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
-    "md_costvol_fwd_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _i, _i, _i, _vp, _ll, _ll, _ll, _ll, _vp]),
-    "md_costvol_bwd_f16": (_i, [_vp, _ll, _ll, _ll, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "md_costvol_fwd": (_i, _CV_FWD),
+    "md_costvol_bwd": (_i, _CV_BWD),
+    "md_costvol_fwd_bf16": (_i, _CV_FWD),
+    "md_costvol_bwd_bf16": (_i, _CV_BWD),
+    "md_costvol_fwd_f16": (_i, _CV_FWD),
+    "md_costvol_bwd_f16": (_i, _CV_BWD),
     "md_fuse_fwd": (_i, [_vp, _i, _i, _i, _i, _i, _ll, _ll, _ll, _ll, _i, _vp, _vp, _vp]),
     "md_fuse_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _ll, _ll, _ll, _ll, _vp, _vp]),
     "md_warp_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),

@@ -108,6 +108,7 @@ struct CvDims {
     // flag equals its wmode (null: every sample)
     const unsigned char *wflags;
     int wmode;
+    int fcl;                     // feature maps and their gradients channels-last [B,h,w,C] (channels-last kernels only)
     long long sb, sd, sg, sp;
 };
 
@@ -739,17 +740,19 @@ struct CvPtrs {
 
 // Launch of the channels-last kernels (costvol_cl.inc).  Grid = the chip's resident workgroup slots for the kernel
 // (occupancy query), each workgroup taking an equal contiguous share of the items x D hypothesis steps.
-template <bool BWD, int N, int LPP, int NW, bool FUSED>
+template <bool BWD, int N, int LPP, int NW, bool FUSED, bool FCL>
 int launch_cl_inst(const CvPtrs &q, const CvDims &dm, hipStream_t stream) {
     CvDims dm2 = dm;
     dm2.k1 = dm2.nc = dm2.fsub = 0;
-    const void *fn = BWD ? (const void *)cl_bwd_kernel<N, LPP, NW, FUSED> : (const void *)cl_fwd_kernel<N, LPP, NW, FUSED>;
+    const void *fn;   // (if constexpr: only the direction's own kernel is instantiated)
+    if constexpr (BWD) fn = (const void *)cl_bwd_kernel<N, LPP, NW, FUSED, FCL>;
+    else fn = (const void *)cl_fwd_kernel<N, LPP, NW, FUSED, FCL>;
     const long long total = (long long)dm.items * dm.D;
     long long nwg = env_int(BWD ? "MD_COSTVOL_NWG_BWD" : "MD_COSTVOL_NWG", 0);
     if (nwg <= 0) {
         // resident workgroup slots of this kernel on this chip, queried once per instantiation (the query costs tens of
         // microseconds of host time per call: with it in every launch the kernel started ~15 us late inside the training step)
-        static long long slots_of[16] = {0};   // per device: a process may drive more than one GPU
+        static long long slots_of[16] = {0};   // per device: a process may drive more than one GPU (static per instantiation)
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
         if (slots_of[dev] == 0) {
@@ -793,13 +796,26 @@ int launch_cl_inst(const CvPtrs &q, const CvDims &dm, hipStream_t stream) {
     if (nwg * ITV_MAX < total) { nwg = (total + ITV_MAX - 1) / ITV_MAX; dm2.k1 = 0; }  // a share fits the interval table
     const dim3 grid((unsigned)nwg), block(64 * NW);
     const char *tname = BWD ? MD_CV_STR(MD_CV_NAME(md_costvol_bwd)) : MD_CV_STR(MD_CV_NAME(md_costvol_fwd));
+    if (BWD) {
+        // d_src is accumulated with atomics from every workgroup whose window covers a cell: zero it.  d_ref is STORED when a
+        // segment is the pixel's only contributor -- true for every segment when each item is one whole-D slice and no other
+        // launch shares the samples -- so it only needs the fill otherwise (config 2: 720 items on 768 slots, k = 1).
+        const bool whole = dm2.k1 == 1 && dm2.fsub == 1 && nwg == dm.items && dm.wflags == nullptr && !MD_CL_DREF_ATOMIC;
+        const size_t bytes = sizeof(float) * (size_t)dm.B * dm.C * dm.h * dm.w;
+        if (!whole && (char *)q.d_ref + bytes == (char *)q.d_src) {
+            MD_CHECK_HIP(hipMemsetAsync(q.d_ref, 0, 2 * bytes, stream));
+        } else {
+            MD_CHECK_HIP(hipMemsetAsync(q.d_src, 0, bytes, stream));
+            if (!whole) MD_CHECK_HIP(hipMemsetAsync(q.d_ref, 0, bytes, stream));
+        }
+    }
     hipEvent_t ev0, ev1;
     md_timing_pair(tname, &ev0, &ev1);
-    if (BWD)
-        hipExtLaunchKernelGGL((cl_bwd_kernel<N, LPP, NW, FUSED>), grid, block, 0, stream, ev0, ev1, 0, q.gout, q.ref, q.src,
+    if constexpr (BWD)
+        hipExtLaunchKernelGGL((cl_bwd_kernel<N, LPP, NW, FUSED, FCL>), grid, block, 0, stream, ev0, ev1, 0, q.gout, q.ref, q.src,
                               q.K, q.invK, q.pose, q.hyp, q.prior, q.ztrans, q.d_ref, q.d_src, dm2);
     else
-        hipExtLaunchKernelGGL((cl_fwd_kernel<N, LPP, NW, FUSED>), grid, block, 0, stream, ev0, ev1, 0, q.ref, q.src, q.K,
+        hipExtLaunchKernelGGL((cl_fwd_kernel<N, LPP, NW, FUSED, FCL>), grid, block, 0, stream, ev0, ev1, 0, q.ref, q.src, q.K,
                               q.invK, q.pose, q.hyp, q.prior, q.ztrans, q.out, dm2);
     MD_CHECK_LAUNCH(BWD ? "md_costvol_bwd (channels-last)" : "md_costvol_fwd (channels-last)");
     return MD_OK;
@@ -816,8 +832,8 @@ template <bool BWD>
 int launch_cl(const CvPtrs &q, CvDims dm, hipStream_t stream) {
     const int N = dm.C / dm.G, LPP = dm.G / 4, TW = 64 / LPP;
     // waves per workgroup: forward 8 (16 x 8 pixel tile), backward 4 (its LDS is 3x the source window per workgroup; measured at
-    // B=6, 48x160, D=96: backward 131 us with 4 against 152 with 8, forward 68 against 62)
-    const int NW = env_int(BWD ? "MD_COSTVOL_CL_NW_BWD" : "MD_COSTVOL_CL_NW", BWD ? 4 : 8) == 4 ? 4 : 8;
+    // B=6, 48x160, D=96: backward 131 us with 4 against 152 with 8, forward 68 against 62).  Only these two are instantiated.
+    constexpr int NW = BWD ? 4 : 8;
     dm.tiles_x = md_cdiv(dm.w, TW);
     dm.tiles = dm.tiles_x * md_cdiv(dm.h, NW);
     dm.splits = 1;
@@ -830,8 +846,14 @@ int launch_cl(const CvPtrs &q, CvDims dm, hipStream_t stream) {
     // thrash the small window; this file's kernel skips them and the first-generation backward takes them in a second launch.
     // With sane poses no sample is flagged and the second launch's workgroups exit at once (~5 us).  MD_COSTVOL_WILD=0 switches
     // the mechanism off, =1 flags every sample.
+    // Planar feature maps only: with channels-last features the kernel itself switches a sub-slice whose footprint exceeds the
+    // window to 16-byte gathers from L2 (cl_stage), no pre-pass, no second launch.
     const int wild_env = env_int("MD_COSTVOL_WILD", -1);
-    const bool wild_ok = BWD && wild_env != 0 && dm.B <= CV_FLAG_MAXB;
+    const bool wild_ok = BWD && !dm.fcl && wild_env != 0 && dm.B <= CV_FLAG_MAXB;
+    if (BWD && !dm.fcl && wild_env != 0 && dm.B > CV_FLAG_MAXB) {
+        static bool warned = false;
+        if (!warned) { warned = true; fprintf(stderr, "movedepth_hip: md_costvol_bwd: B=%d > %d, wild-pose routing off\n", dm.B, CV_FLAG_MAXB); }
+    }
     if (wild_ok) {
         static std::atomic<unsigned> slot_ctr{0};
         unsigned char *flags = nullptr;
@@ -845,12 +867,12 @@ int launch_cl(const CvPtrs &q, CvDims dm, hipStream_t stream) {
     }
 #define MD_CL_F(N_, LPP_)                                                                                        \
     do {                                                                                                         \
-        if (NW == 4)                                                                                             \
-            rc = q.hyp ? launch_cl_inst<BWD, N_, LPP_, 4, false>(q, dm, stream)                                  \
-                       : launch_cl_inst<BWD, N_, LPP_, 4, true>(q, dm, stream);                                  \
+        if (dm.fcl)                                                                                              \
+            rc = q.hyp ? launch_cl_inst<BWD, N_, LPP_, NW, false, true>(q, dm, stream)                           \
+                       : launch_cl_inst<BWD, N_, LPP_, NW, true, true>(q, dm, stream);                           \
         else                                                                                                     \
-            rc = q.hyp ? launch_cl_inst<BWD, N_, LPP_, 8, false>(q, dm, stream)                                  \
-                       : launch_cl_inst<BWD, N_, LPP_, 8, true>(q, dm, stream);                                  \
+            rc = q.hyp ? launch_cl_inst<BWD, N_, LPP_, NW, false, false>(q, dm, stream)                          \
+                       : launch_cl_inst<BWD, N_, LPP_, NW, true, false>(q, dm, stream);                          \
     } while (0)
     int rc = MD_EINVAL;
     bool found = true;
@@ -878,6 +900,20 @@ int launch(const CvPtrs &q, CvDims dm, hipStream_t stream) {
     dm.wflags = nullptr;
     dm.wmode = 0;
     if (cl_eligible(dm, BWD ? (const void *)q.gout : (const void *)q.out)) return launch_cl<BWD>(q, dm, stream);
+    if (dm.fcl) {
+        md_set_error("costvol: channels-last feature maps need the channels-last volume kernels (volume (B,D,h,w,G) with G = 8 or 16, "
+                     "C/G = 1, 2 or 4, 16-byte aligned): got C=%d G=%d strides (%lld,%lld,%lld,%lld)", dm.C, dm.G, dm.sb, dm.sd, dm.sg, dm.sp);
+        return MD_EINVAL;
+    }
+    if (BWD) {   // first-generation backward: both gradients accumulate with atomics
+        const size_t bytes = sizeof(float) * (size_t)dm.B * dm.C * dm.h * dm.w;
+        if ((char *)q.d_ref + bytes == (char *)q.d_src) {
+            MD_CHECK_HIP(hipMemsetAsync(q.d_ref, 0, 2 * bytes, stream));
+        } else {
+            MD_CHECK_HIP(hipMemsetAsync(q.d_src, 0, bytes, stream));
+            MD_CHECK_HIP(hipMemsetAsync(q.d_ref, 0, bytes, stream));
+        }
+    }
     return launch_gen1<BWD>(q, dm, stream, BWD ? MD_CV_STR(MD_CV_NAME(md_costvol_bwd)) : MD_CV_STR(MD_CV_NAME(md_costvol_fwd)));
 }
 
@@ -1020,8 +1056,8 @@ int check_common(const char *fn, const void *ref, const void *src, const void *K
 
 extern "C" int MD_CV_NAME(md_costvol_fwd)(const abi_io_t *ref_, const abi_io_t *src_, const float *K, const float *invK,
                               const float *pose, const float *hyp, const float *prior, const float *ztrans,
-                              float scale_fac, int sched_type, int B, int C, int G, int h, int w, int D, abi_io_t *out_,
-                              long long out_sb, long long out_sd, long long out_sg, long long out_sp,
+                              float scale_fac, int sched_type, int B, int C, int G, int h, int w, int D, int feat_cl,
+                              abi_io_t *out_, long long out_sb, long long out_sd, long long out_sg, long long out_sp,
                               md_stream_t stream) {
     const io_t *ref = reinterpret_cast<const io_t *>(ref_), *src = reinterpret_cast<const io_t *>(src_);
     io_t *out = reinterpret_cast<io_t *>(out_);
@@ -1035,6 +1071,7 @@ extern "C" int MD_CV_NAME(md_costvol_fwd)(const abi_io_t *ref_, const abi_io_t *
     dm.scale_fac = scale_fac; dm.sched_type = sched_type;
     dm.B = B; dm.C = C; dm.G = G; dm.h = h; dm.w = w; dm.D = D;
     dm.sb = out_sb; dm.sd = out_sd; dm.sg = out_sg; dm.sp = out_sp;
+    dm.fcl = feat_cl != 0;
     return launch<false>(q, dm, (hipStream_t)stream);
 }
 
@@ -1042,8 +1079,8 @@ extern "C" int MD_CV_NAME(md_costvol_bwd)(const abi_io_t *gout_, long long g_sb,
                               const abi_io_t *ref_,
                               const abi_io_t *src_, const float *K, const float *invK, const float *pose,
                               const float *hyp, const float *prior, const float *ztrans, float scale_fac,
-                              int sched_type, int B, int C, int G, int h, int w, int D, float *d_ref, float *d_src,
-                              md_stream_t stream) {
+                              int sched_type, int B, int C, int G, int h, int w, int D, int feat_cl, float *d_ref,
+                              float *d_src, md_stream_t stream) {
     const io_t *gout = reinterpret_cast<const io_t *>(gout_), *ref = reinterpret_cast<const io_t *>(ref_),
                *src = reinterpret_cast<const io_t *>(src_);
     int rc = check_common("md_costvol_bwd", ref, src, K, invK, pose, hyp, prior, sched_type, B, C, G, h, w, D);
@@ -1056,13 +1093,8 @@ extern "C" int MD_CV_NAME(md_costvol_bwd)(const abi_io_t *gout_, long long g_sb,
     dm.scale_fac = scale_fac; dm.sched_type = sched_type;
     dm.B = B; dm.C = C; dm.G = G; dm.h = h; dm.w = w; dm.D = D;
     dm.sb = g_sb; dm.sd = g_sd; dm.sg = g_sg; dm.sp = g_sp;
-    const size_t bytes = sizeof(float) * (size_t)B * C * h * w;
-    // one fill when the caller allocated the two gradients back to back (ops.py does): each fill is a 5 us launch
-    if ((char *)d_ref + bytes == (char *)d_src) {
-        MD_CHECK_HIP(hipMemsetAsync(d_ref, 0, 2 * bytes, (hipStream_t)stream));
-    } else {
-        MD_CHECK_HIP(hipMemsetAsync(d_src, 0, bytes, (hipStream_t)stream));
-        MD_CHECK_HIP(hipMemsetAsync(d_ref, 0, bytes, (hipStream_t)stream));
-    }
+    dm.fcl = feat_cl != 0;
+    // the launch paths zero what they accumulate into (one fill when the two gradients sit back to back, as ops.py allocates
+    // them; none for d_ref when the launch stores it)
     return launch<true>(q, dm, (hipStream_t)stream);
 }

@@ -145,6 +145,14 @@ def _vol_logical(store, layout):
 
 _HALF_SUFFIX = {torch.bfloat16: "_bf16", torch.float16: "_f16"}
 
+# False: always hand the plane-sweep kernels planar [B,C,h,w] feature maps (a layout copy when the encoder runs channels_last)
+FEATURES_CHANNELS_LAST = True
+
+
+def _is_cl(t):
+    """4-D tensor stored [B,h,w,C] (and not also [B,C,h,w]-contiguous, as any tensor with C == 1 or h == w == 1 is)."""
+    return t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last) and not t.is_contiguous()
+
 
 class _CostVolume(torch.autograd.Function):
     """Grouped plane-sweep volume; returns a tensor of logical shape (B,D,G,h,w) over `layout` storage."""
@@ -154,21 +162,28 @@ class _CostVolume(torch.autograd.Function):
         # bf16 / fp16 feature maps (mixed-precision configs): the 2-byte build of the kernel reads them and writes a volume
         # of the same type; everything else (and any other dtype) is fp32
         io = ref.dtype if (ref.dtype in _HALF_SUFFIX and src.dtype == ref.dtype) else torch.float32
+        for t, nm in ((ref, "ref"), (src, "src")):
+            if not t.is_cuda:
+                raise _lib.MovedepthHipError("%s must be a GPU tensor (got %s): the HIP path has no CPU fallback" % (nm, t.device))
         if io == torch.float32:
-            ref, src = _prep(ref, "ref"), _prep(src, "src")
+            ref, src = ref.float(), src.float()
+        B, C, h, w = ref.shape
+        # Feature maps in channels_last (memory [B,h,w,C], what FPN4 produces when the 2-D networks run in that format) go to
+        # the kernels as they are -- and d_ref / d_src come back in the same format -- whenever the channels-last-volume
+        # kernels serve the problem; anything else is taken as [B,C,h,w] (one layout copy if it is not).
+        fcl = (layout == "ndhwc" and G in (8, 16) and C % G == 0 and C // G in (1, 2, 4) and FEATURES_CHANNELS_LAST
+               and _is_cl(ref) and (_is_cl(src) or src.is_contiguous()))
+        if fcl:
+            src = src.contiguous(memory_format=torch.channels_last)
         else:
-            for t, nm in ((ref, "ref"), (src, "src")):
-                if not t.is_cuda:
-                    raise _lib.MovedepthHipError("%s must be a GPU tensor (got %s)" % (nm, t.device))
             ref, src = ref.contiguous(), src.contiguous()
         sfx = _HALF_SUFFIX.get(io, "")
         K, invK, pose = _prep(K, "K"), _prep(invK, "invK"), _prep(pose, "pose")
         hyp, prior, ztrans = _prep(hyp, "depth_priors"), _prep(prior, "prior"), _prep(ztrans, "z_trans")
-        B, C, h, w = ref.shape
         store, (sb, sd, sg, sp), out = _vol_alloc(layout, B, D, G, h, w, ref.device, io)
         _timed_call("md_costvol_fwd" + sfx, _p(ref), _p(src), _p(K), _p(invK), _p(pose), _p(hyp), _p(prior), _p(ztrans),
-                    float(scale_fac), int(sched_type), B, C, G, h, w, D, _p(store), sb, sd, sg, sp, _stream())
-        ctx.sfx, ctx.io = sfx, io
+                    float(scale_fac), int(sched_type), B, C, G, h, w, D, int(fcl), _p(store), sb, sd, sg, sp, _stream())
+        ctx.sfx, ctx.io, ctx.fcl = sfx, io, fcl
         ctx.save_for_backward(ref, src, K, invK, pose, hyp if hyp is not None else torch.empty(0),
                               prior if prior is not None else torch.empty(0),
                               ztrans if ztrans is not None else torch.empty(0))
@@ -183,11 +198,14 @@ class _CostVolume(torch.autograd.Function):
         B, C, h, w = ref.shape
         g, (sb, sd, sg, sp) = _vol_as_layout(gout.to(ctx.io), layout)  # no copy when the consumer kept the layout
         # fp32 accumulation (atomics); one allocation, d_ref then d_src: the library zeroes them with a single fill
-        d_both = torch.empty((2,) + tuple(ref.shape), device=ref.device, dtype=torch.float32)
+        if ctx.fcl:   # gradients in the features' own format: (B,C,h,w) views of [B,h,w,C] storage
+            d_both = torch.empty((2, B, h, w, C), device=ref.device, dtype=torch.float32).permute(0, 1, 4, 2, 3)
+        else:
+            d_both = torch.empty((2,) + tuple(ref.shape), device=ref.device, dtype=torch.float32)
         d_ref, d_src = d_both[0], d_both[1]
         _timed_call("md_costvol_bwd" + ctx.sfx, _p(g), sb, sd, sg, sp, _p(ref), _p(src), _p(K), _p(invK), _p(pose),
                     _p(hyp if has_hyp else None), _p(prior if has_prior else None), _p(ztrans if has_z else None),
-                    scale_fac, sched_type, B, C, G, h, w, D, _p(d_ref), _p(d_src), _stream())
+                    scale_fac, sched_type, B, C, G, h, w, D, int(ctx.fcl), _p(d_ref), _p(d_src), _stream())
         return (d_ref.to(ctx.io), d_src.to(ctx.io)) + (None,) * 11
 
 

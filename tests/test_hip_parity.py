@@ -28,6 +28,24 @@ def host(t):
     return t.detach().float().cpu().numpy()
 
 
+# feature-map layouts of the plane sweep: planar [B,C,h,w] and channels-last [B,h,w,C] (md_costvol_*'s feat_cl; what the 2-D
+# encoder produces in torch.channels_last).  The gradients come back in the layout of the features.
+FEATS = ["nchw", "nhwc"]
+
+
+def feat_dev(a, feat, requires_grad=True, dtype=torch.float32):
+    t = torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32).to(dtype).cuda()
+    if feat == "nhwc":
+        t = t.contiguous(memory_format=torch.channels_last)
+        assert t.shape[1] == 1 or not t.is_contiguous()
+    return t.requires_grad_(requires_grad)
+
+
+def check_grad_layout(t, feat):
+    if feat == "nhwc" and t.shape[1] > 1:
+        assert t.grad.is_contiguous(memory_format=torch.channels_last), "gradient should come back channels-last"
+
+
 def kitti_K(h, w, B):
     K = np.array([[0.58 * w, 0, 0.5 * w, 0], [0, 1.92 * h, 0.5 * h, 0], [0, 0, 1, 0], [0, 0, 0, 1]], np.float32)
     invK = np.linalg.pinv(K).astype(np.float32)
@@ -64,12 +82,12 @@ def test_schedule_golden(ops, ty):
 COSTVOL_CASES = ["small", "white", "oob", "zv2", "c64g8"]
 
 
-@pytest.mark.parametrize("layout", ["bgd", "bdg", "ndhwc"])
+@pytest.mark.parametrize("layout,feat", [("bgd", "nchw"), ("bdg", "nchw"), ("ndhwc", "nchw"), ("ndhwc", "nhwc"), ("bdg", "nhwc")])
 @pytest.mark.parametrize("tag", COSTVOL_CASES)
-def test_costvol_golden(ops, tag, layout):
+def test_costvol_golden(ops, tag, layout, feat):
     g = load_golden("costvol_" + tag)
     G = int(g["G"])
-    ref, src = dev(g["ref"], True), dev(g["src0"], True)
+    ref, src = feat_dev(g["ref"], feat), feat_dev(g["src0"], feat)
     vol = ops.costvol_grouped(ref, src, dev(g["K"]), dev(g["invK"]), dev(g["pose"][:, 0]), G,
                               depth_priors=dev(g["hyp"]), layout=layout)
     assert vol.shape == g["grouped0"].shape
@@ -84,7 +102,7 @@ def test_costvol_golden(ops, tag, layout):
     cor_fast, _ = ops.fuse_volumes([vol.detach()], layout=layout)
     assert relerr(host(cor_fast), g["cor_feats"]) < 1e-4
     # ... and its backward (the identity: the term through the confidence weight it drops is O(1e-8) of the gradient)
-    ref2, src2 = dev(g["ref"], True), dev(g["src0"], True)
+    ref2, src2 = feat_dev(g["ref"], feat), feat_dev(g["src0"], feat)
     vol2 = ops.costvol_grouped(ref2, src2, dev(g["K"]), dev(g["invK"]), dev(g["pose"][:, 0]), G, depth_priors=dev(g["hyp"]),
                                layout=layout)
     (ops.fuse_volumes([vol2], layout=layout)[0] * dev(g["grad_out"])).sum().backward()
@@ -101,12 +119,12 @@ def test_costvol_ungrouped_golden(ops):
     assert_close(host(vol), g["cost_vol_full0"])
 
 
-@pytest.mark.parametrize("layout", ["bgd", "ndhwc"])
-def test_costvol_twoframe_golden(ops, layout):
+@pytest.mark.parametrize("layout,feat", [("bgd", "nchw"), ("ndhwc", "nchw"), ("ndhwc", "nhwc")])
+def test_costvol_twoframe_golden(ops, layout, feat):
     g = load_golden("costvol_twoframe")
     G = int(g["G"])
-    ref = dev(g["ref"], True)
-    srcs = [dev(g["src%d" % f], True) for f in range(2)]
+    ref = feat_dev(g["ref"], feat)
+    srcs = [feat_dev(g["src%d" % f], feat) for f in range(2)]
     vols = [ops.costvol_grouped(ref, srcs[f], dev(g["K"]), dev(g["invK"]), dev(g["pose"][:, f]), G,
                                 depth_priors=dev(g["hyp"]), layout=layout) for f in range(2)]
     cor, w = ops.fuse_volumes(vols, layout=layout)
@@ -126,8 +144,9 @@ def test_costvol_twoframe_golden(ops, layout):
     dict(B=1, C=32, G=32, h=12, w=20, D=5, rot=0.02, trans=0.1),              # ungrouped
     dict(B=1, C=64, G=16, h=12, w=20, D=5, rot=0.02, trans=0.1),              # 4 channels per group
 ])
-@pytest.mark.parametrize("fused,layout", [(False, "bgd"), (True, "bgd"), (True, "ndhwc")])
-def test_costvol_vs_oracle(ops, oracle_lib, case, fused, layout):
+@pytest.mark.parametrize("fused,layout,feat", [(False, "bgd", "nchw"), (True, "bgd", "nchw"), (True, "ndhwc", "nchw"),
+                                               (True, "ndhwc", "nhwc"), (False, "ndhwc", "nhwc")])
+def test_costvol_vs_oracle(ops, oracle_lib, case, fused, layout, feat):
     rng = np.random.default_rng(7)
     B, C, G, h, w, D = (case[k] for k in "BCGhwD")
     ref = smooth_field(rng, (B, C, h, w), 3, -1, 1)
@@ -140,7 +159,7 @@ def test_costvol_vs_oracle(ops, oracle_lib, case, fused, layout):
     gout = rng.standard_normal((B, D, G, h, w)).astype(np.float32)
     exp = oracle_lib.costvol_grouped(ref, src, K, invK, hyp, pose, G)
     exp_dref, exp_dsrc = oracle_lib.costvol_grouped_bwd(gout, ref, src, K, invK, hyp, pose)
-    r, s = dev(ref, True), dev(src, True)
+    r, s = feat_dev(ref, feat), feat_dev(src, feat)
     if fused:  # schedule evaluated inside the kernel
         vol = ops.costvol_grouped(r, s, dev(K), dev(invK), dev(pose), G, prior=dev(prior), ndepth=D, scale_fac=0.3,
                                   z_trans=dev(z), type="inverse", layout=layout)
@@ -150,6 +169,8 @@ def test_costvol_vs_oracle(ops, oracle_lib, case, fused, layout):
     (vol * dev(gout)).sum().backward()
     assert_close(host(r.grad), exp_dref, what="d_ref")
     assert_close(host(s.grad), exp_dsrc, what="d_src")
+    if layout == "ndhwc" and C // G in (1, 2, 4) and G in (8, 16):
+        check_grad_layout(r, feat)
 
 
 def relerr_chunked(a, b, chunk=1 << 24):
@@ -187,14 +208,15 @@ def full_size_case(oracle, rng, B, C, G, h, w, D, prior_kind, rot=0.01, trans=0.
                 exp_dsrc=exp_dsrc)
 
 
+@pytest.mark.parametrize("feat", FEATS)
 @pytest.mark.parametrize("prior_kind", ["smooth", "white"])
-def test_costvol_config2_launch_shape_vs_oracle(ops, oracle_lib, prior_kind):
+def test_costvol_config2_launch_shape_vs_oracle(ops, oracle_lib, prior_kind, feat):
     """The launch the bench and the trainer run -- BASELINE config 2: B=6, C=32, G=16, 48x160, D=96, schedule fused,
     channels-last volume, fp32 -- volume, d_ref and d_src against the oracle at 1e-4 (reference layers.py:778-794,
     trainer.py:351-363).  360 workgroup items cut into hypothesis slices: the k-slicing / sub-slice boundaries of this exact
     decomposition are what the small oracle cases cannot reach."""
     c = full_size_case(oracle_lib, np.random.default_rng(21), 6, 32, 16, 48, 160, 96, prior_kind)
-    r, s = dev(c["ref"], True), dev(c["src"], True)
+    r, s = feat_dev(c["ref"], feat), feat_dev(c["src"], feat)
     vol = ops.costvol_grouped(r, s, dev(c["K"]), dev(c["invK"]), dev(c["pose"]), 16, prior=dev(c["prior"]), ndepth=96,
                               scale_fac=0.3, z_trans=dev(c["z"]), type="inverse", layout="ndhwc")
     assert vol.is_contiguous() is False and vol.permute(0, 1, 3, 4, 2).is_contiguous()     # (B,D,h,w,G) storage
@@ -204,10 +226,13 @@ def test_costvol_config2_launch_shape_vs_oracle(ops, oracle_lib, prior_kind):
     vol.backward(dev(c["gout"]))
     assert_close(host(r.grad), c["exp_dref"], what="d_ref")
     assert_close(host(s.grad), c["exp_dsrc"], what="d_src")
+    check_grad_layout(r, feat)
+    check_grad_layout(s, feat)
 
 
+@pytest.mark.parametrize("feat", FEATS)
 @pytest.mark.parametrize("C,B,dtype", [(32, 6, torch.bfloat16), (64, 3, torch.bfloat16), (64, 4, torch.float32)])
-def test_costvol_config4_launch_shapes_vs_oracle(ops, oracle_lib, C, B, dtype):
+def test_costvol_config4_launch_shapes_vs_oracle(ops, oracle_lib, C, B, dtype, feat):
     """BASELINE config 4's volume (80x256 features, D=128) against the oracle at the batch sizes whose launches take the
     schedules the small cases do not: (C=32, B=6, bf16) is the shape with more hypothesis slices than resident workgroup
     slots (two-phase schedule); C=64 -> G=16 is the 4-channels-per-group instantiation, again with more slices than slots
@@ -215,8 +240,7 @@ def test_costvol_config4_launch_shapes_vs_oracle(ops, oracle_lib, C, B, dtype):
     fp32 = dtype == torch.float32
     h, w, D = (48, 160, 96) if fp32 else (80, 256, 128)
     c = full_size_case(oracle_lib, np.random.default_rng(22 + C + B), B, C, 16, h, w, D, "smooth", dtype=None if fp32 else dtype)
-    r = torch.from_numpy(c["ref"]).to(dtype).cuda().requires_grad_(True)
-    s = torch.from_numpy(c["src"]).to(dtype).cuda().requires_grad_(True)
+    r, s = feat_dev(c["ref"], feat, dtype=dtype), feat_dev(c["src"], feat, dtype=dtype)
     vol = ops.costvol_grouped(r, s, dev(c["K"]), dev(c["invK"]), dev(c["pose"]), 16, prior=dev(c["prior"]), ndepth=D,
                               scale_fac=0.3, z_trans=dev(c["z"]), type="inverse", layout="ndhwc")
     assert vol.dtype == dtype
@@ -235,8 +259,9 @@ def test_costvol_config4_launch_shapes_vs_oracle(ops, oracle_lib, C, B, dtype):
     assert relerr(host(s.grad), c["exp_dsrc"]) <= tol
 
 
+@pytest.mark.parametrize("feat", FEATS)
 @pytest.mark.parametrize("w,h", [(256, 80), (512, 160)])
-def test_costvol_wide_coordinates_white_noise(ops, oracle_lib, w, h):
+def test_costvol_wide_coordinates_white_noise(ops, oracle_lib, w, h, feat):
     """The channels-last kernels snap a coordinate within 2^-17 + 5e-7*|coord| px below an integer to that integer
     (csrc/costvol_cl.inc); the band grows with the coordinate.  White-noise features (no smoothness to hide a wrong cell)
     at config 4's widths: 256 (prior_scale 2 of a 1024-px frame) and 512 (prior_scale 1), static and moving camera."""
@@ -252,7 +277,7 @@ def test_costvol_wide_coordinates_white_noise(ops, oracle_lib, w, h):
     gout = rng.standard_normal((B, D, G, h, w)).astype(np.float32)
     exp = oracle_lib.costvol_grouped(ref, src, K, invK, hyp, pose, G)
     exp_dref, exp_dsrc = oracle_lib.costvol_grouped_bwd(gout, ref, src, K, invK, hyp, pose)
-    r, s = dev(ref, True), dev(src, True)
+    r, s = feat_dev(ref, feat), feat_dev(src, feat)
     vol = ops.costvol_grouped(r, s, dev(K), dev(invK), dev(pose), G, prior=dev(prior), ndepth=D, scale_fac=0.3,
                               type="inverse", layout="ndhwc")
     assert_close(host(vol), exp, what="volume")
@@ -261,8 +286,9 @@ def test_costvol_wide_coordinates_white_noise(ops, oracle_lib, w, h):
     assert_close(host(s.grad), exp_dsrc, what="d_src")
 
 
+@pytest.mark.parametrize("feat", FEATS)
 @pytest.mark.parametrize("C", [32, 16, 64])
-def test_costvol_near_prior_carried_sums_vs_oracle(ops, oracle_lib, C):
+def test_costvol_near_prior_carried_sums_vs_oracle(ops, oracle_lib, C, feat):
     """A near scene (prior 0.4-1.2 m, translation 5 cm): the sample position crosses a source cell every few hypotheses, to
     the right for one sample and to the left for the other (a third moves up / down / diagonally).  The backward keeps the
     pending sums of the tap column that the next cell still covers instead of flushing them (csrc/costvol_cl.inc flush_col);
@@ -280,7 +306,7 @@ def test_costvol_near_prior_carried_sums_vs_oracle(ops, oracle_lib, C):
     gout = rng.standard_normal((B, D, G, h, w)).astype(np.float32)
     exp = oracle_lib.costvol_grouped(ref, src, K, invK, hyp, pose, G)
     exp_dref, exp_dsrc = oracle_lib.costvol_grouped_bwd(gout, ref, src, K, invK, hyp, pose)
-    r, s = dev(ref, True), dev(src, True)
+    r, s = feat_dev(ref, feat), feat_dev(src, feat)
     vol = ops.costvol_grouped(r, s, dev(K), dev(invK), dev(pose), G, prior=dev(prior), ndepth=D, scale_fac=0.3, layout="ndhwc")
     assert_close(host(vol), exp, what="volume")
     vol.backward(dev(gout))
@@ -288,7 +314,8 @@ def test_costvol_near_prior_carried_sums_vs_oracle(ops, oracle_lib, C):
     assert_close(host(s.grad), exp_dsrc, what="d_src")
 
 
-def test_costvol_wild_poses_backward_fallback_vs_oracle(ops, oracle_lib):
+@pytest.mark.parametrize("feat", FEATS)
+def test_costvol_wild_poses_backward_fallback_vs_oracle(ops, oracle_lib, feat):
     """Poses of an untrained pose network (axis-angle ~ N(0, 0.3^2) rad, translation ~ N(0, 2^2)): md_costvol_bwd's pre-pass
     flags the samples whose taps would thrash the channels-last kernel's window and hands them to the first-generation backward
     in a second launch (csrc/costvol.hip launch_cl); one sample of the batch keeps a sane pose and stays on the normal kernel.
@@ -307,7 +334,7 @@ def test_costvol_wild_poses_backward_fallback_vs_oracle(ops, oracle_lib):
     exp_dref, exp_dsrc = oracle_lib.costvol_grouped_bwd(gout, ref, src, K, invK, hyp, pose)
     ops.enable_library_kernel_timing(True)
     try:
-        r, s = dev(ref, True), dev(src, True)
+        r, s = feat_dev(ref, feat), feat_dev(src, feat)
         vol = ops.costvol_grouped(r, s, dev(K), dev(invK), dev(pose), G, prior=dev(prior), ndepth=D, scale_fac=0.3, layout="ndhwc")
         assert_close(host(vol), exp, what="volume")
         vol.backward(dev(gout))
@@ -315,14 +342,19 @@ def test_costvol_wild_poses_backward_fallback_vs_oracle(ops, oracle_lib):
         t = ops.library_kernel_times_us(["md_costvol_bwd", "md_costvol_bwd_wild"])
     finally:
         ops.enable_library_kernel_timing(False)
-    assert t["md_costvol_bwd"]["launches"] == 1 and t["md_costvol_bwd_wild"]["launches"] == 1
-    # the second launch did real work (two of three samples), i.e. it is not the empty launch of a sane batch
-    assert t["md_costvol_bwd_wild"]["avg_us"] > 3 * t["md_costvol_bwd"]["avg_us"] or t["md_costvol_bwd_wild"]["avg_us"] > 50, t
+    if feat == "nhwc":
+        # channels-last features: one launch; the kernel switches the wild sub-slices to L2 gathers / atomics by itself
+        assert t["md_costvol_bwd"]["launches"] == 1 and "md_costvol_bwd_wild" not in t, t
+    else:
+        assert t["md_costvol_bwd"]["launches"] == 1 and t["md_costvol_bwd_wild"]["launches"] == 1
+        # the second launch did real work (two of three samples), i.e. it is not the empty launch of a sane batch
+        assert t["md_costvol_bwd_wild"]["avg_us"] > 3 * t["md_costvol_bwd"]["avg_us"] or t["md_costvol_bwd_wild"]["avg_us"] > 50, t
     assert_close(host(r.grad), exp_dref, what="d_ref")
     assert_close(host(s.grad), exp_dsrc, what="d_src")
 
 
-def test_costvol_full_size_properties(ops):
+@pytest.mark.parametrize("feat", FEATS)
+def test_costvol_full_size_properties(ops, feat):
     """BASELINE config 2 size (B=6, 48x160, D=96, C=32, G=16): size-independent properties, beside the oracle comparison of
     the same launch above.
     (1) identity pose => volume == group-mean(ref*src) for every hypothesis (KAT1);
@@ -331,8 +363,9 @@ def test_costvol_full_size_properties(ops):
     B, C, G, h, w, D = 6, 32, 16, 48, 160, 96
     Knp, invKnp = kitti_K(h, w, B)
     K, invK = dev(Knp), dev(invKnp)
-    ref = torch.randn(B, C, h, w, device="cuda")
-    src = torch.randn(B, C, h, w, device="cuda")
+    mf = torch.channels_last if feat == "nhwc" else torch.contiguous_format
+    ref = torch.randn(B, C, h, w, device="cuda").contiguous(memory_format=mf)
+    src = torch.randn(B, C, h, w, device="cuda").contiguous(memory_format=mf)
     prior = 2 + 20 * torch.rand(B, 1, h, w, device="cuda")
     eye = torch.eye(4, device="cuda").repeat(B, 1, 1)
     kw = dict(prior=prior, ndepth=D, scale_fac=0.3, type="inverse", layout="ndhwc")
@@ -342,7 +375,7 @@ def test_costvol_full_size_properties(ops):
     pose = eye.clone()
     pose[:, 0, 3] = 0.05
     pose[:, 2, 3] = 0.03
-    ref2, src2 = torch.randn_like(ref), torch.randn_like(src)
+    ref2, src2 = torch.randn_like(ref), torch.randn_like(src)    # (randn_like keeps the memory format)
     v1 = ops.costvol_grouped(ref, src, K, invK, pose, G, **kw)
     v2 = ops.costvol_grouped(ref2, src, K, invK, pose, G, **kw)
     v12 = ops.costvol_grouped(ref + 2 * ref2, src, K, invK, pose, G, **kw)
@@ -350,7 +383,8 @@ def test_costvol_full_size_properties(ops):
     v3 = ops.costvol_grouped(ref, src2, K, invK, pose, G, **kw)
     v13 = ops.costvol_grouped(ref, src - 3 * src2, K, invK, pose, G, **kw)
     assert relerr(host(v13), host(v1 - 3 * v3)) < 1e-5
-    r, s = ref.clone().requires_grad_(True), src.clone().requires_grad_(True)
+    r, s = ref.clone().requires_grad_(True), src.clone().requires_grad_(True)   # (clone keeps the memory format)
+    assert r.is_contiguous(memory_format=mf)
     v = ops.costvol_grouped(r, s, K, invK, pose, G, **kw)
     g = torch.randn_like(v)
     (v * g).sum().backward()
@@ -668,9 +702,9 @@ def test_standalone_geometry_modules_golden(ops):
     dict(B=2, C=16, G=16, h=10, w=20, D=6),     # one channel per group, 16 channels
     dict(B=1, C=8, G=2, h=10, w=20, D=6),       # 4 channels per group, 2 groups (no group-quad map)
 ])
-@pytest.mark.parametrize("layout", ["bdg", "ndhwc"])
+@pytest.mark.parametrize("layout,feat", [("bdg", "nchw"), ("ndhwc", "nchw"), ("ndhwc", "nhwc")])
 @pytest.mark.parametrize("sched", ["inverse", "linear", "log"])
-def test_costvol_ragged_shapes(ops, oracle_lib, case, layout, sched):
+def test_costvol_ragged_shapes(ops, oracle_lib, case, layout, sched, feat):
     rng = np.random.default_rng(29)
     B, C, G, h, w, D = (case[k] for k in "BCGhwD")
     ref = smooth_field(rng, (B, C, h, w), 2, -1, 1)
@@ -685,7 +719,7 @@ def test_costvol_ragged_shapes(ops, oracle_lib, case, layout, sched):
     exp = oracle_lib.costvol_grouped(ref, src, K, invK, hyp, pose, G)
     gout = rng.standard_normal(exp.shape).astype(np.float32)
     exp_dref, exp_dsrc = oracle_lib.costvol_grouped_bwd(gout, ref, src, K, invK, hyp, pose)
-    r, s = dev(ref, True), dev(src, True)
+    r, s = feat_dev(ref, feat), feat_dev(src, feat)
     vol = ops.costvol_grouped(r, s, dev(K), dev(invK), dev(pose), G, prior=dev(prior), ndepth=D, scale_fac=0.3,
                               z_trans=dev(z), type=sched, layout=layout)
     assert vol.shape == exp.shape
@@ -1072,11 +1106,11 @@ def test_reg3d_fused_bn_paths_agree(ops):
 
 # ------------------------------------------------------------------ cost volume with 2-byte feature maps / volume
 @pytest.mark.parametrize("dtype,tol_rounded,tol_exact", [(torch.bfloat16, 1.5e-3, 4e-3), (torch.float16, 2e-4, 5e-4)])
-@pytest.mark.parametrize("fused,layout", [(False, "bgd"), (True, "bgd"), (True, "ndhwc")])
+@pytest.mark.parametrize("fused,layout,feat", [(False, "bgd", "nchw"), (True, "bgd", "nchw"), (True, "ndhwc", "nchw"), (True, "ndhwc", "nhwc")])
 @pytest.mark.parametrize("case", [dict(B=2, C=32, G=16, h=24, w=40, D=12), dict(B=1, C=32, G=16, h=48, w=160, D=16),
                                   dict(B=1, C=32, G=16, h=24, w=40, D=13),   # odd slice: the unpaired tail of the 16-byte store path
                                   dict(B=1, C=16, G=8, h=24, w=40, D=11)])   # two lanes per pixel
-def test_costvol_half_io_vs_oracle(ops, oracle_lib, case, fused, layout, dtype, tol_rounded, tol_exact):
+def test_costvol_half_io_vs_oracle(ops, oracle_lib, case, fused, layout, feat, dtype, tol_rounded, tol_exact):
     """BASELINE configs 4 / 5 precision: bf16 or fp16 feature maps and volume, fp32 arithmetic in between.  The oracle gets
     the *rounded* features as floats; the kernel's output must equal the oracle's fp32 volume rounded to the format (a
     result within fp32 noise of a rounding boundary may land on the neighbouring value: norm-wise bound `tol_rounded`,
@@ -1093,7 +1127,7 @@ def test_costvol_half_io_vs_oracle(ops, oracle_lib, case, fused, layout, dtype, 
     gout_t = torch.from_numpy(rng.standard_normal((B, D, G, h, w)).astype(np.float32)).to(dtype)
     exp = oracle_lib.costvol_grouped(ref, src, K, invK, hyp, pose, G)
     exp_dref, exp_dsrc = oracle_lib.costvol_grouped_bwd(gout_t.float().numpy(), ref, src, K, invK, hyp, pose)
-    r, s = ref_t.cuda().requires_grad_(True), src_t.cuda().requires_grad_(True)
+    r, s = feat_dev(ref, feat, dtype=dtype), feat_dev(src, feat, dtype=dtype)
     if fused:
         vol = ops.costvol_grouped(r, s, dev(K), dev(invK), dev(pose), G, prior=dev(prior), ndepth=D, scale_fac=0.3, layout=layout)
     else:

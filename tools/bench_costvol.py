@@ -39,6 +39,8 @@ def main():
     ap.add_argument("--prior", default=os.environ.get("PRIOR", "white"), choices=["white", "smooth", "const"],
                     help="depth prior: white noise per pixel in [2,22) (adversarial: neighbouring pixels sweep unrelated epipolar "
                          "segments), a smooth field (what the mono decoder produces), or a constant")
+    ap.add_argument("--feat", default=os.environ.get("FEAT", "nhwc"), choices=["nchw", "nhwc"],
+                    help="feature-map layout: planar [B,C,h,w] or channels-last [B,h,w,C] (what the encoder produces in channels_last)")
     ap.add_argument("--rotate", type=int, default=8,
                     help="write into N different output buffers in turn (N x 283 MB >> the 256 MB Infinity Cache), so that a "
                          "launch cannot benefit from lines of its own output left in cache by the previous launch")
@@ -50,8 +52,9 @@ def main():
     invK = torch.linalg.pinv(K)
     tdt = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}[a.dtype]
     eb = 4 if a.dtype == "f32" else 2
-    ref = torch.randn(B, C, h, w, device=dev).to(tdt).requires_grad_(True)
-    src = torch.randn(B, C, h, w, device=dev).to(tdt).requires_grad_(True)
+    mf = torch.channels_last if a.feat == "nhwc" else torch.contiguous_format
+    ref = torch.randn(B, C, h, w, device=dev).to(tdt).contiguous(memory_format=mf).requires_grad_(True)
+    src = torch.randn(B, C, h, w, device=dev).to(tdt).contiguous(memory_format=mf).requires_grad_(True)
     if a.prior == "white":
         prior = 2 + 20 * torch.rand(B, 1, h, w, device=dev)
     elif a.prior == "smooth":
@@ -113,7 +116,7 @@ def main():
     lib_t = ops.library_kernel_times_us(["md_costvol_fwd" + sfx, "md_costvol_bwd" + sfx, "md_costvol_bwd_wild" + sfx])
     ops.enable_library_kernel_timing(False)
     env = {k: v for k, v in os.environ.items() if k.startswith("MD_")}
-    print("costvol B=%d %dx%d D=%d C=%d G=%d fused=%d layout=%s dtype=%s prior=%s env=%s" % (B, h, w, D, C, G, a.fused, a.layout, a.dtype, a.prior, env))
+    print("costvol B=%d %dx%d D=%d C=%d G=%d fused=%d layout=%s feat=%s dtype=%s prior=%s env=%s" % (B, h, w, D, C, G, a.fused, a.layout, a.feat, a.dtype, a.prior, env))
     print("  fwd %8.1f us  %7.1f MB  %7.0f GB/s (%.1f%% of 8 TB/s)" % (tf, fbytes / 1e6, fbytes / tf / 1e3, fbytes / tf / 1e3 / 80))
     print("  bwd %8.1f us  %7.1f MB  %7.0f GB/s (%.1f%% of 8 TB/s)  [includes 2 memsets + autograd glue]" % (tb, bbytes / 1e6, bbytes / tb / 1e3, bbytes / tb / 1e3 / 80))
     if os.environ.get("MD_CV_STATS"):
