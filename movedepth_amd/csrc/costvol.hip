@@ -109,6 +109,9 @@ struct CvDims {
     const unsigned char *wflags;
     int wmode;
     int fcl;                     // feature maps and their gradients channels-last [B,h,w,C] (channels-last kernels only)
+    int xcd_map;                 // item-aligned slices: contiguous ranges per XCD (cv_share)
+    float gslack0;               // fcl: ... and by this factor already at the first (whole-slice) attempt: no halving
+    float gslack;                // fcl: a sub-slice whose footprint exceeds the window by this factor is gathered from L2 (cl_stage)
     long long sb, sd, sg, sp;
 };
 
@@ -154,7 +157,14 @@ __device__ __forceinline__ void cv_share(const CvDims &dm, long long &lo, long l
         hi = total * (blockIdx.x + 1) / gridDim.x;
         return;
     }
-    const int bid = blockIdx.x;
+    int bid = blockIdx.x;
+    if (dm.xcd_map && bid < dm.nc) {
+        // workgroup b runs on XCD b % 8 (observed): give every XCD a CONTIGUOUS eighth of the slices, i.e. neighbouring tiles of
+        // one sample, so that the d_src lines its atomics touch (and the source lines its windows / gathers read) stay in that
+        // XCD's L2 instead of bouncing between the eight of them
+        const int x = bid & 7, n8 = dm.nc >> 3, r = dm.nc & 7;
+        bid = x * n8 + min(x, r) + (bid >> 3);
+    }
     const int sl = bid < dm.nc ? bid : dm.nc + (bid - dm.nc) / dm.fsub;  // coarse slice
     const int item = sl / dm.k1, part = sl - item * dm.k1;
     const long long l0 = (long long)item * dm.D + (long long)part * dm.D / dm.k1;
@@ -163,7 +173,7 @@ __device__ __forceinline__ void cv_share(const CvDims &dm, long long &lo, long l
         lo = l0;
         hi = l1;
     } else {
-        const int sub = (bid - dm.nc) % dm.fsub;
+        const int sub = ((int)blockIdx.x - dm.nc) % dm.fsub;
         lo = l0 + (l1 - l0) * sub / dm.fsub;
         hi = l0 + (l1 - l0) * (sub + 1) / dm.fsub;
     }
@@ -899,6 +909,12 @@ template <bool BWD>
 int launch(const CvPtrs &q, CvDims dm, hipStream_t stream) {
     dm.wflags = nullptr;
     dm.wmode = 0;
+    static const float gslack = [] { const char *e = getenv("MD_COSTVOL_GATHER_SLACK"); const float f = (e && *e) ? (float)atof(e) : MD_CL_GATHER_SLACK; return f > 0.f ? f : MD_CL_GATHER_SLACK; }();
+    dm.gslack = gslack;
+    static const int xcd_map = env_int(BWD ? "MD_COSTVOL_XCD_MAP_BWD" : "MD_COSTVOL_XCD_MAP", 0);
+    dm.xcd_map = xcd_map;
+    static const float gslack0 = [] { const char *e = getenv("MD_COSTVOL_GATHER_SLACK0"); return (e && *e) ? (float)atof(e) : 1e9f; }();
+    dm.gslack0 = gslack0;
     if (cl_eligible(dm, BWD ? (const void *)q.gout : (const void *)q.out)) return launch_cl<BWD>(q, dm, stream);
     if (dm.fcl) {
         md_set_error("costvol: channels-last feature maps need the channels-last volume kernels (volume (B,D,h,w,G) with G = 8 or 16, "

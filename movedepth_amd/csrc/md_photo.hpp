@@ -39,6 +39,7 @@ __device__ __forceinline__ float div9(float x) { return div_by(x, 9.f, 1.f / 9.f
 
 // F.interpolate(bilinear, align_corners=False) source taps of output index o (trainer.py:512)
 __device__ __forceinline__ void interp_idx(int o, int in, int out, int &i0, int &i1, float &l1) {
+#pragma clang fp contract(off)
     const float scale = (float)in / (float)out;
     float s = scale * ((float)o + 0.5f) - 0.5f;
     if (s < 0.f) s = 0.f;
@@ -51,6 +52,7 @@ __device__ __forceinline__ void interp_idx(int o, int in, int out, int &i0, int 
 
 // the same with scale = (float)in / (float)out hoisted by the caller (wave-uniform: one IEEE division per kernel, not two per pixel)
 __device__ __forceinline__ void interp_idx_s(int o, int in, float scale, int &i0, int &i1, float &l1) {
+#pragma clang fp contract(off)
     float s = scale * ((float)o + 0.5f) - 0.5f;
     if (s < 0.f) s = 0.f;
     int a = (int)s;
@@ -60,16 +62,29 @@ __device__ __forceinline__ void interp_idx_s(int o, int in, float scale, int &i0
     l1 = s - (float)a;
 }
 
+// F.interpolate's four taps in the reference's order (the oracle's mdo_resize_bilinear_fwd; pinned by the depth maps of
+// tests/golden/losses_mono.npz): the north-east product first, then nw, sw, se accumulated with fused multiply-adds
+__device__ __forceinline__ float interp4(float nw, float ne, float sw, float se, float lx, float ly) {
+#pragma clang fp contract(off)
+    const float wy0 = 1.f - ly, wx0 = 1.f - lx;
+    float o = (wy0 * lx) * ne;
+    o = fmaf(wy0 * wx0, nw, o);
+    o = fmaf(ly * wx0, sw, o);
+    o = fmaf(ly * lx, se, o);
+    return o;
+}
+
 // upsampled disparity at (y, x) of the full-resolution grid -> scaled disparity sd (depth = 1 / sd, layers.py:400-409)
 __device__ __forceinline__ float disp_up_sd(const float *__restrict__ s, int h, int w, int H, int W, int y, int x,
                                             float min_disp, float max_disp) {
+    // no contraction: the oracle's (mdo_resize_bilinear_fwd, mdo_disp_to_depth) operations one by one -- the depth feeds the
+    // projection, whose sample positions are asserted bit-equal to the oracle's
+#pragma clang fp contract(off)
     int x0, x1, y0, y1;
     float lx, ly;
     interp_idx_s(x, w, (float)w / (float)W, x0, x1, lx);   // the quotients are wave-uniform: hoisted out of any loop
     interp_idx_s(y, h, (float)h / (float)H, y0, y1, ly);
-    const float v = (1.f - ly) * ((1.f - lx) * s[y0 * w + x0] + lx * s[y0 * w + x1]) +
-                    ly * ((1.f - lx) * s[y1 * w + x0] + lx * s[y1 * w + x1]);
-    return min_disp + (max_disp - min_disp) * v;
+    return min_disp + (max_disp - min_disp) * interp4(s[y0 * w + x0], s[y0 * w + x1], s[y1 * w + x0], s[y1 * w + x1], lx, ly);
 }
 
 struct Moments {

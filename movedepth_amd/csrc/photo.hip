@@ -60,7 +60,10 @@ __device__ __forceinline__ Sample3 sample_border(const float4 *__restrict__ img,
     Sample3 o;
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
-        float a = f4c(v00, ch) * (wy0 * wx0);   // explicit fma chain, as warp_fwd_kernel: bit-equal results
+        // grid_sample's interpolation in the reference's order (as warp_fwd_kernel and the oracle's tap_sample: bit-equal results);
+        // a tap that is out of range adds an exact zero
+#pragma clang fp contract(off)
+        float a = f4c(v00, ch) * (wy0 * wx0);
         a = fmaf(vx1 ? f4c(v01, ch) : 0.f, wy0 * t.wx1, a);
         a = fmaf(vy1 ? f4c(v10, ch) : 0.f, t.wy1 * wx0, a);
         a = fmaf((vx1 && vy1) ? f4c(v11, ch) : 0.f, t.wy1 * t.wx1, a);
@@ -91,8 +94,11 @@ __device__ __forceinline__ void load_cams(const md_photo_desc &a, int b, float *
         const int f = tid / 12, i = (tid % 12) / 4, j = tid % 4;
         const float *K = a.K + b * 16, *T = a.T[f] + b * 16;
         float sum = 0.f;
+        {
+#pragma clang fp contract(off)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) sum = fmaf(K[i * 4 + k], T[k * 4 + j], sum);   // as md_load_cam
+            for (int k = 0; k < 4; ++k) sum = sum + K[i * 4 + k] * T[k * 4 + j];   // as md_load_cam_plain (= the oracle's kt_rows)
+        }
         camS[tid] = sum;
     } else if (tid < 12 * F + 9) {
         const int k = tid - 12 * F;

@@ -21,7 +21,7 @@ __global__ __launch_bounds__(256) void warp_fwd_kernel(const float *__restrict__
     const int b = blockIdx.z;
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= W || y >= H) return;
-    const CamMats cam = md_load_cam(K + b * 16, invK + b * 16, T + b * 16);
+    const CamMats cam = md_load_cam_plain(K + b * 16, invK + b * 16, T + b * 16);
     const size_t HW = (size_t)H * W, p = (size_t)y * W + x;
     float r0, r1, r2;
     md_ray(cam, (float)x, (float)y, r0, r1, r2);
@@ -34,6 +34,9 @@ __global__ __launch_bounds__(256) void warp_fwd_kernel(const float *__restrict__
     const bool vx1 = x1 < W, vy1 = y1 < H;  // x0,y0 are in range after clipping
     const float wx0 = 1.f - t.wx1, wy0 = 1.f - t.wy1;
     for (int ch = 0; ch < Ci; ++ch) {
+        // grid_sample's interpolation in the reference's order (nw product, then fused multiply-adds of ne, sw, se: the order
+        // the fixtures pin, md_common.hpp / oracle tap_sample): the warped frame is bit-equal to the oracle's and the reference's
+#pragma clang fp contract(off)
         const float *im = img + ((size_t)b * Ci + ch) * HW;
         float o = im[t.y0 * W + t.x0] * (wy0 * wx0);
         if (vx1) o = fmaf(im[t.y0 * W + x1], wy0 * t.wx1, o);
@@ -53,7 +56,7 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(const float *__restrict__
     const int b = blockIdx.z;
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     const bool valid = x < W && y < H;
-    const CamMats cam = md_load_cam(K + b * 16, invK + b * 16, T + b * 16);
+    const CamMats cam = md_load_cam_plain(K + b * 16, invK + b * 16, T + b * 16);
     const size_t HW = (size_t)H * W, p = (size_t)y * W + x;
     float dP[12];
 #pragma unroll
@@ -149,10 +152,12 @@ __global__ __launch_bounds__(256) void disp_up_fwd_kernel(const float *__restric
     interp_idx(x, w, W, x0, x1, lx);
     interp_idx(y, h, H, y0, y1, ly);
     const float *s = disp + (size_t)b * h * w;
-    const float v = (1.f - ly) * ((1.f - lx) * s[y0 * w + x0] + lx * s[y0 * w + x1]) +
-                    ly * ((1.f - lx) * s[y1 * w + x0] + lx * s[y1 * w + x1]);
-    const float sd = min_disp + (max_disp - min_disp) * v;
-    depth[((size_t)b * H + y) * W + x] = 1.f / sd;
+    {   // the oracle's operations one by one (mdo_resize_bilinear_fwd, mdo_disp_to_depth)
+#pragma clang fp contract(off)
+        const float v = interp4(s[y0 * w + x0], s[y0 * w + x1], s[y1 * w + x0], s[y1 * w + x1], lx, ly);
+        const float sd = min_disp + (max_disp - min_disp) * v;
+        depth[((size_t)b * H + y) * W + x] = 1.f / sd;
+    }
 }
 
 // Gather form of the adjoint (deterministic, no atomics): LPP lanes per low-res pixel scan the full-res pixels whose
@@ -189,8 +194,7 @@ __global__ __launch_bounds__(256) void disp_up_bwd_kernel(const float *__restric
             const float wx = (x0 == ix ? 1.f - lx : 0.f) + (x1 == ix ? lx : 0.f);
             if (wx == 0.f) continue;
             // recompute the forward value at (oy, ox): depth = 1/sd, d depth / d v = -(max-min) / sd^2
-            const float v = (1.f - ly) * ((1.f - lx) * s[y0 * w + x0] + lx * s[y0 * w + x1]) +
-                            ly * ((1.f - lx) * s[y1 * w + x0] + lx * s[y1 * w + x1]);
+            const float v = interp4(s[y0 * w + x0], s[y0 * w + x1], s[y1 * w + x0], s[y1 * w + x1], lx, ly);
             const float sd = min_disp + (max_disp - min_disp) * v;
             const float gv = -g_depth[((size_t)b * H + oy) * W + ox] * (max_disp - min_disp) / (sd * sd);
             acc += gv * wy * wx;

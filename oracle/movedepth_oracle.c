@@ -55,19 +55,30 @@ static void kt_rows(const float *K, const float *T, float P[12]) {
         }
 }
 
+/* Operation order of the three matrix products on the path.  The reference writes them as torch.matmul (layers.py:582, 608,
+ * 610); what arithmetic that is, is decided by the BLAS behind it, and the committed fixtures -- the reference's own outputs --
+ * are the pin: tools/diag/op_order_search.py evaluates every combination of {each product and sum rounded, fused multiply-add
+ * chain ascending, descending} against the 20,720 pixel coordinates held by tests/golden/{warp_small, warp_border, geometry,
+ * losses_mono}.npz; exactly ONE combination reproduces them, all of them, bit for bit:
+ *   P = K @ T (4x4 by 4x4: the small-matrix path)        -- every product and sum rounded on its own (kt_rows above);
+ *   inv_K[:3,:3] @ (x, y, 1) and P @ (X, Y, Z, 1) (sgemm)  -- acc = a0 b0, then acc = fma(a_k, b_k, acc), k ascending.
+ * This file is compiled with -ffp-contract=off, so the only fused operations are the fmaf calls written here. */
+static inline float dot3_fma(const float *a, float x, float y) { return fmaf(a[1], y, a[0] * x) + a[2]; }
+static inline float dot4_fma(const float *a, float X, float Y, float Z) { return fmaf(a[2], Z, fmaf(a[1], Y, a[0] * X)) + a[3]; }
+
 /* One pixel through BackprojectDepth (layers.py:581-586) and Project3D (layers.py:608-620).
  * Returns the normalised grid coordinates (gx, gy); optionally the camera point (X,Y,Z). */
 static inline void project_pixel(const float *invK, const float *P, float x, float y, float d, float eps,
                                  int w, int h, float *gx, float *gy, float *X3) {
     /* inv_K[:3,:3] @ (x, y, 1) */
-    float r0 = invK[0] * x + invK[1] * y + invK[2];
-    float r1 = invK[4] * x + invK[5] * y + invK[6];
-    float r2 = invK[8] * x + invK[9] * y + invK[10];
+    float r0 = dot3_fma(invK, x, y);
+    float r1 = dot3_fma(invK + 4, x, y);
+    float r2 = dot3_fma(invK + 8, x, y);
     float X = d * r0, Y = d * r1, Z = d * r2; /* depth * cam_points, layers.py:583 */
     if (X3) { X3[0] = X; X3[1] = Y; X3[2] = Z; }
-    float c0 = P[0] * X + P[1] * Y + P[2] * Z + P[3];
-    float c1 = P[4] * X + P[5] * Y + P[6] * Z + P[7];
-    float c2 = P[8] * X + P[9] * Y + P[10] * Z + P[11];
+    float c0 = dot4_fma(P, X, Y, Z);
+    float c1 = dot4_fma(P + 4, X, Y, Z);
+    float c2 = dot4_fma(P + 8, X, Y, Z);
     float zz = c2 + eps;                       /* layers.py:612 */
     float u = c0 / zz, v = c1 / zz;
     u = u / (float)(w - 1);                    /* layers.py:618 */
@@ -215,11 +226,16 @@ static inline float tap_sample(const float *img, int w, int h, const tap_t *t) {
     float wx0 = 1.f - t->wx1, wy0 = 1.f - t->wy1;
     int x0 = t->x0, y0 = t->y0, x1 = x0 + 1, y1 = y0 + 1;
     int vx0 = x0 >= 0 && x0 < w, vx1 = x1 >= 0 && x1 < w, vy0 = y0 >= 0 && y0 < h, vy1 = y1 >= 0 && y1 < h;
-    float o = 0.f;
-    if (vx0 && vy0) o += img[y0 * w + x0] * (wy0 * wx0);
-    if (vx1 && vy0) o += img[y0 * w + x1] * (wy0 * t->wx1);
-    if (vx0 && vy1) o += img[y1 * w + x0] * (t->wy1 * wx0);
-    if (vx1 && vy1) o += img[y1 * w + x1] * (t->wy1 * t->wx1);
+    /* grid_sample's interpolation as the reference's build evaluates it -- nw_val * nw, then fused multiply-adds of the ne,
+     * sw, se taps in that order, out-of-range taps valued 0 -- found the same way as the matrix products' order above
+     * (tools/diag/op_order_search.py: the only one of five candidate orders that reproduces the 30,720 warped values of
+     * tests/golden/{warp_small, warp_border, losses_mono}.npz bit for bit) */
+    float nw = (vx0 && vy0) ? img[y0 * w + x0] : 0.f, ne = (vx1 && vy0) ? img[y0 * w + x1] : 0.f;
+    float sw = (vx0 && vy1) ? img[y1 * w + x0] : 0.f, se = (vx1 && vy1) ? img[y1 * w + x1] : 0.f;
+    float o = nw * (wy0 * wx0);
+    o = fmaf(ne, wy0 * t->wx1, o);
+    o = fmaf(sw, t->wy1 * wx0, o);
+    o = fmaf(se, t->wy1 * t->wx1, o);
     return o;
 }
 
@@ -505,11 +521,10 @@ void mdo_warp_bwd(const float *gout, const float *img, const float *depth, const
             for (int x = 0; x < W; ++x) {
                 int p = y * W + x;
                 float d = depth[(size_t)b * HW + p];
-                float r0 = iK[0] * x + iK[1] * y + iK[2], r1 = iK[4] * x + iK[5] * y + iK[6],
-                      r2 = iK[8] * x + iK[9] * y + iK[10];
+                float r0 = dot3_fma(iK, (float)x, (float)y), r1 = dot3_fma(iK + 4, (float)x, (float)y),
+                      r2 = dot3_fma(iK + 8, (float)x, (float)y);          /* as project_pixel */
                 float X = d * r0, Y = d * r1, Z = d * r2;
-                float c0 = P[0] * X + P[1] * Y + P[2] * Z + P[3], c1 = P[4] * X + P[5] * Y + P[6] * Z + P[7],
-                      c2 = P[8] * X + P[9] * Y + P[10] * Z + P[11];
+                float c0 = dot4_fma(P, X, Y, Z), c1 = dot4_fma(P + 4, X, Y, Z), c2 = dot4_fma(P + 8, X, Y, Z);
                 float zz = c2 + 1e-7f;
                 float u = c0 / zz, v = c1 / zz;
                 float gx = (u / (float)(W - 1) - 0.5f) * 2.f, gy = (v / (float)(H - 1) - 0.5f) * 2.f;
@@ -568,8 +583,17 @@ void mdo_resize_bilinear_fwd(const float *in, int N, int h, int w, int H, int W,
                 int x0, x1; float lx;
                 interp_idx(x, w, W, &x0, &x1, &lx);
                 const float *s = in + (size_t)n * h * w;
-                out[((size_t)n * H + y) * W + x] = (1.f - ly) * ((1.f - lx) * s[y0 * w + x0] + lx * s[y0 * w + x1]) +
-                                                  ly * ((1.f - lx) * s[y1 * w + x0] + lx * s[y1 * w + x1]);
+                /* the four taps in the order the reference's build evaluates them (found like the matrix products' order,
+                 * tools/diag/op_order_search.py: of the 24 fused-multiply-add chains over the taps only this one reproduces
+                 * F.interpolate and the depth_0_{1,2,3} maps of tests/golden/losses_mono.npz bit for bit): the north-east
+                 * product first, then nw, sw, se accumulated with fused multiply-adds.  The weights are products of the two
+                 * axes' weights (exact for the power-of-two pyramid ratios the trainer uses). */
+                float wy0 = 1.f - ly, wx0 = 1.f - lx;
+                float o = (wy0 * lx) * s[y0 * w + x1];
+                o = fmaf(wy0 * wx0, s[y0 * w + x0], o);
+                o = fmaf(ly * wx0, s[y1 * w + x0], o);
+                o = fmaf(ly * lx, s[y1 * w + x1], o);
+                out[((size_t)n * H + y) * W + x] = o;
             }
         }
 }

@@ -11,9 +11,10 @@ def test_geometry(oracle_lib):
     g = load_golden("geometry")
     B, _, h, w = g["depth"].shape
     cam, pix = oracle_lib.backproject_project(g["depth"], g["invK"], g["K"], g["T"], h, w)
-    assert_close(cam, g["cam_points"], what="cam_points")
-    # pix in [-1,1]: compare in pixel units so the tolerance means something
-    assert_close(pix, g["pix_coords"], rtol=1e-5, what="pix_coords")
+    # bit for bit: the oracle evaluates the reference's three matrix products in the operation order the fixtures pin
+    # (oracle/movedepth_oracle.c project_pixel, tools/diag/op_order_search.py)
+    assert np.array_equal(cam, g["cam_points"]), "cam_points not bit-equal to the reference's"
+    assert np.array_equal(pix, g["pix_coords"]), "%d pix_coords differ from the reference's bit patterns" % int((pix != g["pix_coords"]).sum())
     eye = np.repeat(np.eye(4, dtype=np.float32)[None], B, 0)
     _, pix_id = oracle_lib.backproject_project(g["depth"], g["invK"], g["K"], eye, h, w)
     assert_close(pix_id, g["pix_coords_identity"], rtol=1e-5, what="KAT6 identity grid")
@@ -124,8 +125,9 @@ def test_costvol_kat_identity_and_shift(oracle_lib):
 def test_warp(oracle_lib, tag):
     g = load_golden("warp_" + tag)
     out, pix = oracle_lib.warp(g["img"], g["depth"], g["K"], g["invK"], g["T"])
-    assert_close(pix, g["pix_coords"], rtol=1e-5, what="pix")
-    assert_close(out, g["warped"], what="warped")
+    # sample positions and warped frame: bit-equal to the reference's own (every texel decision included)
+    assert np.array_equal(pix, g["pix_coords"]), "%d sample coordinates differ from the reference's bit patterns" % int((pix != g["pix_coords"]).sum())
+    assert np.array_equal(out, g["warped"]), "%d warped values differ from the reference's bit patterns" % int((out != g["warped"]).sum())
     mask = ((pix < -1) | (pix > 1)).sum(-1) > 0
     assert int((mask != g["mvs_mask"]).sum()) == 0  # bit-exact on the fixtures
     d_depth, d_T = oracle_lib.warp_bwd(g["grad_out"], g["img"], g["depth"], g["K"], g["invK"], g["T"])
@@ -225,3 +227,21 @@ def test_eval_fusion_matches_the_reference_expression(oracle_lib):
         wsum = wsum + cw
         acc = acc + cw.unsqueeze(1).unsqueeze(1) * t
     assert_close(cor, (acc / wsum.unsqueeze(1).unsqueeze(1)).numpy(), rtol=1e-6)
+
+
+def test_mono_chain_bit_equal_to_the_reference(oracle_lib):
+    """The reference Trainer's own generate_images_pred (trainer.py:510-532) on the losses_mono fixture: up-sampled disparity ->
+    depth at every pyramid level, the sample grid and the warped frame of both source frames -- the oracle reproduces all of
+    them BIT FOR BIT (F.interpolate's tap order, the matrix products' fused multiply-adds, grid_sample's interpolation order:
+    tools/diag/op_order_search.py).  Texel decisions of the oracle are therefore the reference's."""
+    g = load_golden("losses_mono")
+    H, W = g["in_color_0_0"].shape[2:]
+    for s in range(4):
+        _, depth = oracle_lib.disp_to_depth(oracle_lib.resize_bilinear(g["disp_%d" % s], H, W), 0.1, 100.0)
+        assert np.array_equal(depth.reshape(g["depth_0_%d" % s].shape), g["depth_0_%d" % s]), "depth at scale %d" % s
+    for tag, f in (("m1", -1), ("p1", 1)):
+        out, pix = oracle_lib.warp(g["in_color_%d_0" % f], g["depth_0_0"], g["in_K_0"], g["in_inv_K_0"], g["T_" + tag])
+        assert np.array_equal(pix, g["sample_%s_0" % tag]), tag
+        assert np.array_equal(out, g["color_%s_0" % tag]), tag
+        out3, _ = oracle_lib.warp(g["in_color_%d_0" % f], g["depth_0_3"], g["in_K_0"], g["in_inv_K_0"], g["T_" + tag])
+        assert np.array_equal(out3, g["color_%s_3" % tag]), tag
