@@ -397,14 +397,6 @@ int c16_dims(const char *fn, int B, int Ci, int Co, int D, int H, int W, C16Dims
 
 }  // namespace
 
-// Launch with the measurement hook of capi.hip: when md_kernel_timing_enable(1) is on, a start / stop event pair is tied to THIS dispatch
-// (its own begin / end timestamps, what rocprofv3's kernel trace reads) and recorded under the entry point's name; otherwise a plain launch.
-#define MD_LAUNCH_TIMED(tname, kern, grid, block, lds, s, ...)                                   \
-    do {                                                                                         \
-        hipEvent_t e0_, e1_;                                                                     \
-        md_timing_pair(tname, &e0_, &e1_);                                                       \
-        hipExtLaunchKernelGGL(kern, grid, block, lds, s, e0_, e1_, 0, __VA_ARGS__);              \
-    } while (0)
 
 extern "C" {
 

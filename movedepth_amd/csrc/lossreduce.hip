@@ -204,26 +204,28 @@ int smooth_check(const char *fn, const SmoothArgs &a) {
 }
 
 int smooth_fwd_launch(const SmoothArgs &a, float *loss, void *ws, hipStream_t st) {
+    const char *TN_ = a.S > 1 ? "md_smooth_multi_fwd" : "md_smooth_fwd";
     if (a.normalize) {
-        hipLaunchKernelGGL(smooth_mean_kernel, dim3(SM_BLK, a.B, a.S), dim3(256), 0, st, a, (float *)ws);
+        MD_LAUNCH_TIMED(TN_, smooth_mean_kernel, dim3(SM_BLK, a.B, a.S), dim3(256), 0, st, a, (float *)ws);
         MD_CHECK_LAUNCH("md_smooth_fwd(mean)");
     }
-    hipLaunchKernelGGL(smooth_fwd_kernel, dim3(SM_BLK, a.B, a.S), dim3(256), 0, st, a, (float *)ws);
+    MD_LAUNCH_TIMED(TN_, smooth_fwd_kernel, dim3(SM_BLK, a.B, a.S), dim3(256), 0, st, a, (float *)ws);
     MD_CHECK_LAUNCH("md_smooth_fwd");
-    hipLaunchKernelGGL(smooth_finish_kernel, dim3(a.S), dim3(256), 0, st, a, (const float *)ws, loss);
+    MD_LAUNCH_TIMED(TN_, smooth_finish_kernel, dim3(a.S), dim3(256), 0, st, a, (const float *)ws, loss);
     MD_CHECK_LAUNCH("md_smooth_fwd(finish)");
     return MD_OK;
 }
 
 int smooth_bwd_launch(const SmoothArgs &a, void *ws, hipStream_t st) {
+    const char *TN_ = a.S > 1 ? "md_smooth_multi_bwd" : "md_smooth_bwd";
     if (a.normalize) {  // recompute the means: the workspace need not survive between forward and backward
-        hipLaunchKernelGGL(smooth_mean_kernel, dim3(SM_BLK, a.B, a.S), dim3(256), 0, st, a, (float *)ws);
+        MD_LAUNCH_TIMED(TN_, smooth_mean_kernel, dim3(SM_BLK, a.B, a.S), dim3(256), 0, st, a, (float *)ws);
         MD_CHECK_LAUNCH("md_smooth_bwd(mean)");
     }
-    hipLaunchKernelGGL(smooth_bwd_kernel, dim3(SM_BLK, a.B, a.S), dim3(256), 0, st, a, (float *)ws);
+    MD_LAUNCH_TIMED(TN_, smooth_bwd_kernel, dim3(SM_BLK, a.B, a.S), dim3(256), 0, st, a, (float *)ws);
     MD_CHECK_LAUNCH("md_smooth_bwd");
     if (a.normalize) {
-        hipLaunchKernelGGL(smooth_bwd_finish_kernel, dim3(SM_BLK, a.B, a.S), dim3(256), 0, st, a, (const float *)ws);
+        MD_LAUNCH_TIMED(TN_, smooth_bwd_finish_kernel, dim3(SM_BLK, a.B, a.S), dim3(256), 0, st, a, (const float *)ws);
         MD_CHECK_LAUNCH("md_smooth_bwd(finish)");
     }
     return MD_OK;

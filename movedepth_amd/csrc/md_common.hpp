@@ -40,6 +40,15 @@ unsigned long long *md_stats_buffer();  // capi.hip: device counters for md_cost
 // kernel timing hook (capi.hip): start / stop events for hipExtLaunchKernelGGL, null unless md_kernel_timing_enable(1)
 void md_timing_pair(const char *name, hipEvent_t *start, hipEvent_t *stop);
 
+// Launch with the measurement hook of capi.hip: when md_kernel_timing_enable(1) is on, a start / stop event pair is tied to THIS dispatch
+// (its own begin / end timestamps, what rocprofv3's kernel trace reads) and recorded under `tname`; otherwise a plain launch.
+#define MD_LAUNCH_TIMED(tname, kern, grid, block, lds, s, ...)                                   \
+    do {                                                                                         \
+        hipEvent_t e0_, e1_;                                                                     \
+        md_timing_pair(tname, &e0_, &e1_);                                                       \
+        hipExtLaunchKernelGGL(kern, grid, block, lds, s, e0_, e1_, 0, __VA_ARGS__);              \
+    } while (0)
+
 static inline int md_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 // ---------------------------------------------------------------- geometry (device)

@@ -731,7 +731,7 @@ extern "C" int md_pack_rgbx(const float *const *imgs, int n, int B, int H, int W
         a.out[k] = out[k];
     }
     a.n = n; a.HW = (long long)H * W; a.BHW = a.HW * B;
-    hipLaunchKernelGGL(pack_rgbx_kernel, dim3((unsigned)md_cdiv(a.BHW, 256 * 2), n), dim3(256), 0, (hipStream_t)stream, a);
+    MD_LAUNCH_TIMED("md_pack_rgbx", pack_rgbx_kernel, dim3((unsigned)md_cdiv(a.BHW, 256 * 2), n), dim3(256), 0, (hipStream_t)stream, a);
     MD_CHECK_LAUNCH("md_pack_rgbx");
     return MD_OK;
 }
@@ -755,14 +755,14 @@ extern "C" int md_photo_fwd(const md_photo_desc *d, void *ws, md_stream_t stream
     hipStream_t st = (hipStream_t)stream;
 #define MD_PH_FWD(F_)                                                                                                       \
     do {                                                                                                                    \
-        if (d->identity) hipLaunchKernelGGL((photo_fwd_kernel<F_, true>), grid, dim3(256), lds, st, *d, (float *)ws);       \
-        else hipLaunchKernelGGL((photo_fwd_kernel<F_, false>), grid, dim3(256), lds, st, *d, (float *)ws);                  \
+        if (d->identity) MD_LAUNCH_TIMED("md_photo_fwd", (photo_fwd_kernel<F_, true>), grid, dim3(256), lds, st, *d, (float *)ws); \
+        else MD_LAUNCH_TIMED("md_photo_fwd", (photo_fwd_kernel<F_, false>), grid, dim3(256), lds, st, *d, (float *)ws);     \
     } while (0)
     if (F == 1) MD_PH_FWD(1); else if (F == 2) MD_PH_FWD(2); else if (F == 3) MD_PH_FWD(3); else MD_PH_FWD(4);
 #undef MD_PH_FWD
     MD_CHECK_LAUNCH("md_photo_fwd");
     if (!d->identity) {
-        hipLaunchKernelGGL(photo_fwd_finish_kernel, dim3(S), dim3(256), 0, st, (const float *)ws, tiles * d->B, d->loss);
+        MD_LAUNCH_TIMED("md_photo_fwd", photo_fwd_finish_kernel, dim3(S), dim3(256), 0, st, (const float *)ws, tiles * d->B, d->loss);
         MD_CHECK_LAUNCH("md_photo_fwd(finish)");
     }
     return MD_OK;
@@ -789,15 +789,15 @@ extern "C" int md_photo_bwd(const md_photo_desc *d, void *ws, md_stream_t stream
     float *gup = wsP + (size_t)12 * d->S * F * d->B * nblk;
     const size_t lds = sizeof(float4) * ((size_t)(1 + F) * B2_N + 3 * B1_N);
     hipStream_t st = (hipStream_t)stream;
-    if (F == 1) hipLaunchKernelGGL((photo_bwd_kernel<1>), grid, dim3(256), lds, st, *d, gup, wsP);
-    else if (F == 2) hipLaunchKernelGGL((photo_bwd_kernel<2>), grid, dim3(256), lds, st, *d, gup, wsP);
-    else if (F == 3) hipLaunchKernelGGL((photo_bwd_kernel<3>), grid, dim3(256), lds, st, *d, gup, wsP);
-    else hipLaunchKernelGGL((photo_bwd_kernel<4>), grid, dim3(256), lds, st, *d, gup, wsP);
+    if (F == 1) MD_LAUNCH_TIMED("md_photo_bwd", (photo_bwd_kernel<1>), grid, dim3(256), lds, st, *d, gup, wsP);
+    else if (F == 2) MD_LAUNCH_TIMED("md_photo_bwd", (photo_bwd_kernel<2>), grid, dim3(256), lds, st, *d, gup, wsP);
+    else if (F == 3) MD_LAUNCH_TIMED("md_photo_bwd", (photo_bwd_kernel<3>), grid, dim3(256), lds, st, *d, gup, wsP);
+    else MD_LAUNCH_TIMED("md_photo_bwd", (photo_bwd_kernel<4>), grid, dim3(256), lds, st, *d, gup, wsP);
     MD_CHECK_LAUNCH("md_photo_bwd");
     bool any_T = false;
     for (int f = 0; f < F; ++f) any_T |= d->d_T[f] != nullptr;
     if (any_T) {
-        hipLaunchKernelGGL(photo_bwd_finish_kernel, dim3(d->B, F), dim3(256), 0, st, *d, (const float *)wsP, nblk);
+        MD_LAUNCH_TIMED("md_photo_bwd", photo_bwd_finish_kernel, dim3(d->B, F), dim3(256), 0, st, *d, (const float *)wsP, nblk);
         MD_CHECK_LAUNCH("md_photo_bwd(finish)");
     }
     if (d->is_disp) {
@@ -808,7 +808,7 @@ extern "C" int md_photo_bwd(const md_photo_desc *d, void *ws, md_stream_t stream
             const long long n = (long long)d->B * d->dh[s] * d->dw[s] * lpp;
             mx = n > mx ? n : mx;
         }
-        hipLaunchKernelGGL(up_adjoint_kernel, dim3((unsigned)md_cdiv(mx, 256), d->S), dim3(256), 0, st, *d, (const float *)gup);
+        MD_LAUNCH_TIMED("md_photo_bwd", up_adjoint_kernel, dim3((unsigned)md_cdiv(mx, 256), d->S), dim3(256), 0, st, *d, (const float *)gup);
         MD_CHECK_LAUNCH("md_photo_bwd(up-sampling adjoint)");
     }
     return MD_OK;

@@ -83,7 +83,7 @@ class KITTIRAWDataset(torch.utils.data.Dataset):
         self.frame_idxs, self.num_scales = list(frame_idxs), int(num_scales)
         self.is_train, self.img_ext = bool(is_train), img_ext
         self.K = KITTI_K
-        self.seed = int(seed)   # kept for call compatibility: the draws come from the process-global generators, see __getitem__
+        self.seed = int(seed)   # folded into the loader's generator (make_loader); the draws themselves come from the process-global generators, see __getitem__
 
     def __len__(self):
         return len(self.filenames)
@@ -153,6 +153,22 @@ def make_loader(dataset, batch_size, rank=0, world_size=1, shuffle=True, num_wor
     if world_size > 1:
         sampler = torch.utils.data.distributed.DistributedSampler(dataset, num_replicas=world_size, rank=rank, shuffle=shuffle,
                                                                   seed=seed)
+    # Augmentation draws come from the process-global generators, as in the reference (see MonoDataset.__getitem__), and
+    # train.py seeds every rank alike: without more, all ranks (and worker i of every rank) would draw the same flip / jitter
+    # stream.  The loader's own generator -- from which DataLoader derives each worker's base seed -- therefore folds in the
+    # rank and the dataset's seed, and worker_init_fn carries that base seed to python's and numpy's generators (torch's is
+    # seeded by DataLoader itself).  With num_workers = 0 the draws are the main process's, seeded alike on every rank by train.py exactly as upstream (train.py:8-19).
+    gen = torch.Generator()
+    gen.manual_seed(int(seed) + 7919 * int(getattr(dataset, "seed", 0)) + 1000003 * int(rank))
+
+    def _seed_worker(_worker_id):
+        import random
+
+        base = torch.initial_seed() % (2 ** 32)
+        random.seed(base)
+        np.random.seed(base)
+
     loader = torch.utils.data.DataLoader(dataset, batch_size, shuffle=(shuffle and sampler is None), sampler=sampler,
-                                         num_workers=num_workers, pin_memory=True, drop_last=drop_last)
+                                         num_workers=num_workers, pin_memory=True, drop_last=drop_last, generator=gen,
+                                         worker_init_fn=_seed_worker if num_workers > 0 else None)
     return loader, sampler

@@ -434,8 +434,13 @@ def _ptr(t):
 
 
 def is_packed(img):
-    """(B,H,W,4) contiguous float32 RGBx: the image layout of the fused photometric kernels"""
-    return img.dim() == 4 and img.shape[-1] == 4 and img.shape[1] != 3 and img.dtype == torch.float32 and img.is_contiguous()
+    """(B,H,W,4) contiguous float32 RGBx: the image layout of the fused photometric kernels.  Told from a planar (B,3,H,W) frame
+    by shape; the one shape that reads both ways -- (B,3,X,4): a planar frame 4 pixels wide or a packed one 3 rows high -- is
+    rejected instead of guessed."""
+    if img.dim() == 4 and img.shape[-1] == 4 and img.shape[1] == 3:
+        raise _lib.MovedepthHipError("image of shape %s is ambiguous (planar (B,3,H,4) or packed (B,3,W,4)): frames must be "
+                                     "wider than 4 pixels and higher than 3" % (tuple(img.shape),))
+    return img.dim() == 4 and img.shape[-1] == 4 and img.dtype == torch.float32 and img.is_contiguous()
 
 
 def packed_view(p):

@@ -285,10 +285,16 @@ class Trainer:
             z_trans = z_trans.reshape(-1).contiguous()
         sched = dict(prior=depth_prior, ndepth=opt.num_depth_bins, scale_fac=opt.depth_bin_fac, z_trans=z_trans,
                      type=opt.schedule_type)
-        # Only the first / last hypothesis planes are needed outside the kernel (localmax endpoints).  The schedule's interval
-        # position of bin k is k / (D - 1): 0 for the first and 1 for the last bin whatever D is (also in the 'log' spacing), so a
-        # two-bin schedule IS those two planes, bit for bit -- 0.2 MB instead of the (B,D,h,w) tensor (17.7 MB, 14 us per step).
-        end_planes = ops.schedule_depth_range(depth_prior, 2, opt.depth_bin_fac, z_trans, opt.schedule_type)
+        # Only the first / last hypothesis planes are needed outside the kernel (localmax endpoints).  For the inverse and linear
+        # spacings the interval position of bin k is k / (D - 1): exactly 0 for the first and 1 for the last bin whatever D is, so
+        # a two-bin schedule IS those two planes, bit for bit -- 0.2 MB instead of the (B,D,h,w) tensor (17.7 MB, 14 us per step).
+        # The 'log' spacing evaluates exp(log .1 + (log 10 * k) / (D - 1)) left to right (layers.py:277): (a * 95) / 95 need not
+        # round to a, so there the end planes are taken from the full schedule.
+        if opt.schedule_type == "log":
+            full = ops.schedule_depth_range(depth_prior, opt.num_depth_bins, opt.depth_bin_fac, z_trans, opt.schedule_type)
+            end_planes = torch.stack([full[:, 0], full[:, -1]], 1)
+        else:
+            end_planes = ops.schedule_depth_range(depth_prior, 2, opt.depth_bin_fac, z_trans, opt.schedule_type)
         min_inv, max_inv = 1 / end_planes[:, 1], 1 / end_planes[:, 0]  # swapped on purpose (App. B-6)
 
         def mvs_branch(ref_feat, want_prob=False):

@@ -304,12 +304,13 @@ void mdo_costvol_grouped_fwd(const float *ref, const float *src, const float *K,
                              const float *hyp, const float *pose, int B, int C, int G, int h, int w, int D,
                              float *out) {
     int hw = h * w, n = C / G;
-#pragma omp parallel for collapse(2) schedule(static)
+    /* every output element is independent: threads over (sample, plane, row), so that ONE sample keeps all cores busy */
+#pragma omp parallel for collapse(3) schedule(static)
     for (int b = 0; b < B; ++b)
-        for (int d = 0; d < D; ++d) {
-            float P[12];
-            kt_rows(K + b * 16, pose + b * 16, P);
-            for (int y = 0; y < h; ++y)
+        for (int d = 0; d < D; ++d)
+            for (int y = 0; y < h; ++y) {
+                float P[12];
+                kt_rows(K + b * 16, pose + b * 16, P);
                 for (int x = 0; x < w; ++x) {
                     int p = y * w + x;
                     float gx, gy;
@@ -337,26 +338,50 @@ void mdo_costvol_grouped_bwd(const float *gout, const float *ref, const float *s
     int hw = h * w, n = C / G;
     memset(d_ref, 0, sizeof(float) * (size_t)B * C * hw);
     memset(d_src, 0, sizeof(float) * (size_t)B * C * hw);
+    /* Threads over (row, column segment) of one sample at a time: a pixel -- hence its d_ref entries -- belongs to one thread;
+     * the d_src scatter goes into a thread-private copy of the sample's gradient (no atomics), and the copies are added up in
+     * thread order afterwards (deterministic for a given thread count).  XS column segments per row so that 48 rows feed
+     * hundreds of threads. */
+    int T = mdo_num_threads();
+    const int XS = 8;
+    float *priv = T > 1 ? (float *)calloc((size_t)T * C * hw, sizeof(float)) : NULL;
+    for (int b = 0; b < B; ++b) {
+        float P[12];
+        kt_rows(K + b * 16, pose + b * 16, P);
 #pragma omp parallel for collapse(2) schedule(static)
-    for (int b = 0; b < B; ++b)
-        for (int y = 0; y < h; ++y) {
-            float P[12];
-            kt_rows(K + b * 16, pose + b * 16, P);
-            for (int d = 0; d < D; ++d)
-                for (int x = 0; x < w; ++x) {
-                    int p = y * w + x;
-                    float gx, gy;
-                    project_pixel(invK + b * 16, P, (float)x, (float)y, hyp[((size_t)b * D + d) * hw + p], 1e-7f, w,
-                                  h, &gx, &gy, NULL);
-                    tap_t t = make_tap(gx, gy, w, h, 0);
-                    for (int c = 0; c < C; ++c) {
-                        float g = gout[(((size_t)b * D + d) * G + (c % G)) * hw + p] / (float)n;
-                        size_t o = ((size_t)b * C + c) * hw;
-                        d_ref[o + p] += g * tap_sample(src + o, w, h, &t); /* row y is owned by this thread */
-                        tap_scatter_atomic(d_src + o, w, h, &t, g * ref[o + p]);
+        for (int y = 0; y < h; ++y)
+            for (int xs = 0; xs < XS; ++xs) {
+#ifdef _OPENMP
+                float *ds = priv ? priv + (size_t)omp_get_thread_num() * C * hw : d_src + (size_t)b * C * hw;
+#else
+                float *ds = d_src + (size_t)b * C * hw;
+#endif
+                int xa = (int)((long long)w * xs / XS), xb = (int)((long long)w * (xs + 1) / XS);
+                for (int d = 0; d < D; ++d)
+                    for (int x = xa; x < xb; ++x) {
+                        int p = y * w + x;
+                        float gx, gy;
+                        project_pixel(invK + b * 16, P, (float)x, (float)y, hyp[((size_t)b * D + d) * hw + p], 1e-7f, w,
+                                      h, &gx, &gy, NULL);
+                        tap_t t = make_tap(gx, gy, w, h, 0);
+                        for (int c = 0; c < C; ++c) {
+                            float g = gout[(((size_t)b * D + d) * G + (c % G)) * hw + p] / (float)n;
+                            size_t o = ((size_t)b * C + c) * hw;
+                            d_ref[o + p] += g * tap_sample(src + o, w, h, &t); /* pixel p is owned by this thread */
+                            tap_scatter(ds + (size_t)c * hw, w, h, &t, g * ref[o + p]);
+                        }
                     }
-                }
+            }
+        if (priv) {
+#pragma omp parallel for schedule(static)
+            for (int i = 0; i < C * hw; ++i) {
+                float acc = 0.f;
+                for (int t = 0; t < T; ++t) { acc += priv[(size_t)t * C * hw + i]; priv[(size_t)t * C * hw + i] = 0.f; }
+                d_src[(size_t)b * C * hw + i] = acc;
+            }
         }
+    }
+    free(priv);
 }
 
 /* Confidence-weighted frame fusion, trainer.py:349-363.
@@ -488,11 +513,11 @@ void mdo_fuse_bwd(const float *gout, const float *const *vols, int N, int B, int
 void mdo_warp_fwd(const float *img, const float *depth, const float *K, const float *invK, const float *T, int B,
                   int Ci, int H, int W, float *pix, float *out) {
     int HW = H * W;
-#pragma omp parallel for schedule(static)
-    for (int b = 0; b < B; ++b) {
-        float P[12];
-        kt_rows(K + b * 16, T + b * 16, P);
-        for (int y = 0; y < H; ++y)
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int b = 0; b < B; ++b)
+        for (int y = 0; y < H; ++y) {
+            float P[12];
+            kt_rows(K + b * 16, T + b * 16, P);
             for (int x = 0; x < W; ++x) {
                 int p = y * W + x;
                 float gx, gy;
@@ -503,7 +528,7 @@ void mdo_warp_fwd(const float *img, const float *depth, const float *K, const fl
                 for (int c = 0; c < Ci; ++c)
                     out[((size_t)b * Ci + c) * HW + p] = tap_sample(img + ((size_t)b * Ci + c) * HW, W, H, &t);
             }
-    }
+        }
 }
 
 /* Autograd of mdo_warp_fwd w.r.t. depth and T (the image is an input, no grad).  SURVEY App. A.2.
@@ -517,6 +542,9 @@ void mdo_warp_bwd(const float *gout, const float *img, const float *depth, const
         const float *iK = invK + b * 16;
         kt_rows(K + b * 16, T + b * 16, P);
         for (int i = 0; i < 12; ++i) dP[i] = 0.0;
+        /* rows over threads; the 12 sums of dL/dP are double-precision reductions (their order depends on the thread count:
+         * ~1e-16 relative) */
+#pragma omp parallel for schedule(static) reduction(+ : dP[:12])
         for (int y = 0; y < H; ++y)
             for (int x = 0; x < W; ++x) {
                 int p = y * W + x;
@@ -662,7 +690,7 @@ void mdo_ssim(const float *x, const float *y, int N, int H, int W, float *out) {
 void mdo_reproj_loss_fwd(const float *pred, const float *target, int B, int C, int H, int W, float ssim_w,
                          int no_ssim, float *out) {
     int HW = H * W;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for collapse(2) schedule(static)
     for (int b = 0; b < B; ++b)
         for (int py = 0; py < H; ++py)
             for (int px = 0; px < W; ++px) {
@@ -682,50 +710,80 @@ void mdo_reproj_loss_fwd(const float *pred, const float *target, int B, int C, i
             }
 }
 
-/* Autograd of mdo_reproj_loss_fwd w.r.t. pred.  gout [B,H,W]; d_pred [B,C,H,W]. */
+/* Autograd of mdo_reproj_loss_fwd w.r.t. pred.  gout [B,H,W]; d_pred [B,C,H,W].
+ * Two passes, both over (plane, row) so that one sample keeps all cores busy and no atomics are needed: (1) per window p the
+ * three coefficients of d SSIM-term / d(mu_x, E[x^2], E[xy]) times the upstream factor; (2) per pixel q the sum over the
+ * windows that contain q -- with ReflectionPad2d(1) a border window reads some pixels more than once: multiplicity
+ * refl_mult() per axis -- plus the L1 term. */
+static inline int refl_mult(int p, int q, int n) {
+    int m = 0;
+    for (int d = -1; d <= 1; ++d) m += reflect1(p + d, n) == q;
+    return m;
+}
 void mdo_reproj_loss_bwd(const float *gout, const float *pred, const float *target, int B, int C, int H, int W,
                          float ssim_w, int no_ssim, float *d_pred) {
     int HW = H * W;
-    memset(d_pred, 0, sizeof(float) * (size_t)B * C * HW);
-#pragma omp parallel for collapse(2) schedule(static)
-    for (int b = 0; b < B; ++b)
-        for (int c = 0; c < C; ++c) {
-            const float *xp = pred + ((size_t)b * C + c) * HW, *yp = target + ((size_t)b * C + c) * HW;
-            float *dx = d_pred + ((size_t)b * C + c) * HW;
-            for (int py = 0; py < H; ++py)
-                for (int px = 0; px < W; ++px) {
-                    int p = py * W + px;
-                    float g = gout[(size_t)b * HW + p];
-                    float diff = yp[p] - xp[p];
-                    float sg = diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f);
-                    float wl1 = no_ssim ? 1.f : (1.f - ssim_w);
-                    dx[p] += -sg * g * wl1 / (float)C;
-                    if (no_ssim || ssim_w == 0.f) continue;
-                    ssim_stats_t s = ssim_stats(xp, yp, H, W, py, px);
-                    float n, d;
-                    ssim_value(&s, &n, &d);
-                    float raw = (1.f - n / d) / 2.f;
-                    if (raw < 0.f || raw > 1.f) continue; /* clamp: zero gradient outside [0,1] */
-                    float gs = g * ssim_w / (float)C;
-                    float sx = s.ex2 - s.mux * s.mux, sy = s.ey2 - s.muy * s.muy, sxy = s.exy - s.mux * s.muy;
-                    float A1 = 2.f * s.mux * s.muy + SSIM_C1, A2 = 2.f * sxy + SSIM_C2;
-                    float B1 = s.mux * s.mux + s.muy * s.muy + SSIM_C1, B2 = sx + sy + SSIM_C2;
-                    /* s = (1 - n/d)/2 ; ds = -(dn*d - n*dd)/(2 d^2) */
-                    float dn_dmux = 2.f * s.muy * A2 - 2.f * s.muy * A1;
-                    float dd_dmux = 2.f * s.mux * B2 - 2.f * s.mux * B1;
-                    float ca = -0.5f * (dn_dmux * d - n * dd_dmux) / (d * d); /* d s / d mu_x   */
-                    float cb = 0.5f * n * B1 / (d * d);                        /* d s / d E[x^2] */
-                    float cc = -0.5f * (2.f * A1) / d;                         /* d s / d E[xy]  */
-                    for (int dy = -1; dy <= 1; ++dy)
-                        for (int ddx = -1; ddx <= 1; ++ddx) {
-                            int yy = reflect1(py + dy, H), xx = reflect1(px + ddx, W);
-                            int q = yy * W + xx;
-                            float contrib = gs * (ca + 2.f * cb * xp[q] + cc * yp[q]) / 9.f;
-#pragma omp atomic
-                            dx[q] += contrib;
-                        }
+    int use_ssim = !(no_ssim || ssim_w == 0.f);
+    float *co = use_ssim ? (float *)malloc(sizeof(float) * 3 * (size_t)B * C * HW) : NULL;
+    if (use_ssim) {
+#pragma omp parallel for collapse(3) schedule(static)
+        for (int b = 0; b < B; ++b)
+            for (int c = 0; c < C; ++c)
+                for (int py = 0; py < H; ++py) {
+                    const float *xp = pred + ((size_t)b * C + c) * HW, *yp = target + ((size_t)b * C + c) * HW;
+                    float *ca_ = co + 3 * ((size_t)b * C + c) * HW, *cb_ = ca_ + HW, *cc_ = cb_ + HW;
+                    for (int px = 0; px < W; ++px) {
+                        int p = py * W + px;
+                        ca_[p] = cb_[p] = cc_[p] = 0.f;
+                        ssim_stats_t s = ssim_stats(xp, yp, H, W, py, px);
+                        float n, d;
+                        ssim_value(&s, &n, &d);
+                        float raw = (1.f - n / d) / 2.f;
+                        if (raw < 0.f || raw > 1.f) continue; /* clamp: zero gradient outside [0,1] */
+                        float gs = gout[(size_t)b * HW + p] * ssim_w / (float)C;
+                        float sx = s.ex2 - s.mux * s.mux, sy = s.ey2 - s.muy * s.muy, sxy = s.exy - s.mux * s.muy;
+                        float A1 = 2.f * s.mux * s.muy + SSIM_C1, A2 = 2.f * sxy + SSIM_C2;
+                        float B1 = s.mux * s.mux + s.muy * s.muy + SSIM_C1, B2 = sx + sy + SSIM_C2;
+                        /* s = (1 - n/d)/2 ; ds = -(dn*d - n*dd)/(2 d^2) */
+                        float dn_dmux = 2.f * s.muy * A2 - 2.f * s.muy * A1;
+                        float dd_dmux = 2.f * s.mux * B2 - 2.f * s.mux * B1;
+                        ca_[p] = gs * (-0.5f * (dn_dmux * d - n * dd_dmux) / (d * d)); /* d s / d mu_x   */
+                        cb_[p] = gs * (0.5f * n * B1 / (d * d));                        /* d s / d E[x^2] */
+                        cc_[p] = gs * (-0.5f * (2.f * A1) / d);                         /* d s / d E[xy]  */
+                    }
                 }
-        }
+    }
+#pragma omp parallel for collapse(3) schedule(static)
+    for (int b = 0; b < B; ++b)
+        for (int c = 0; c < C; ++c)
+            for (int qy = 0; qy < H; ++qy) {
+                const float *xp = pred + ((size_t)b * C + c) * HW, *yp = target + ((size_t)b * C + c) * HW;
+                float *dx = d_pred + ((size_t)b * C + c) * HW;
+                const float *ca_ = use_ssim ? co + 3 * ((size_t)b * C + c) * HW : NULL, *cb_ = ca_ + HW, *cc_ = cb_ + HW;
+                float wl1 = no_ssim ? 1.f : (1.f - ssim_w);
+                for (int qx = 0; qx < W; ++qx) {
+                    int q = qy * W + qx;
+                    float diff = yp[q] - xp[q];
+                    float sg = diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f);
+                    float acc = -sg * gout[(size_t)b * HW + q] * wl1 / (float)C;
+                    if (use_ssim) {
+                        for (int py = qy - 2; py <= qy + 2; ++py) {
+                            if (py < 0 || py >= H) continue;
+                            int my = refl_mult(py, qy, H);
+                            if (!my) continue;
+                            for (int px = qx - 2; px <= qx + 2; ++px) {
+                                if (px < 0 || px >= W) continue;
+                                int mx = refl_mult(px, qx, W);
+                                if (!mx) continue;
+                                int p = py * W + px;
+                                acc += (float)(my * mx) * ((ca_[p] + 2.f * cb_[p] * xp[q] + cc_[p] * yp[q]) / 9.f);
+                            }
+                        }
+                    }
+                    dx[q] = acc;
+                }
+            }
+    free(co);
 }
 
 /* ------------------------------------------------------------------ min / automask / masked mean */

@@ -74,8 +74,14 @@ def test_schedule_golden(ops, ty):
     full = ops.schedule_depth_range(dev(g["prior"]), D, f, dev(g["z_trans"]), ty)
     assert_close(host(full), g["zv2_" + ty], rtol=1e-5)
     # the trainer asks for the first / last planes only, as a two-bin schedule (interval positions 0 and 1 whatever D): bit-equal
+    # for the inverse and linear spacings; the log spacing's last position is exp(log .1 + (log 10 * (D-1)) / (D-1)), which need
+    # not round to the two-bin value -- the trainer takes the full schedule's end planes there (trainer.py process_batch)
     ends = ops.schedule_depth_range(dev(g["prior"]), 2, f, dev(g["z_trans"]), ty)
-    assert torch.equal(ends[:, 0], full[:, 0]) and torch.equal(ends[:, 1], full[:, -1])
+    assert torch.equal(ends[:, 0], full[:, 0])
+    if ty != "log":
+        assert torch.equal(ends[:, 1], full[:, -1])
+    else:
+        assert_close(host(ends[:, 1]), host(full[:, -1]), rtol=1e-6)
 
 
 # ------------------------------------------------------------------ cost volume
