@@ -44,6 +44,33 @@ def costvol_fwd_bytes(B, C, G, h, w, D, fused, eb=4):
     return 2 * eb * B * C * h * w + hyp + eb * B * D * G * h * w + 192 * B
 
 
+def usable_cpus():
+    """CPUs this process can actually keep busy: the affinity mask, capped by the cgroup's CPU-time quota (a container that sees
+    256 hardware threads but is granted 16 CPUs' worth of time runs 128 OpenMP threads SLOWER than one: measured on the pool's
+    boxes, tools/diag/cpu_scaling_probe.py).  -> (count, description)"""
+    import math
+
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    desc = "no cgroup CPU quota"
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            lim = max(1, int(math.ceil(int(q) / int(per))))
+            desc = "cgroup quota %s/%s = %d CPUs" % (q, per, lim)
+            n = min(n, lim)
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                lim = max(1, int(math.ceil(q / per)))
+                desc = "cgroup quota %d/%d = %d CPUs" % (q, per, lim)
+                n = min(n, lim)
+        except Exception:
+            pass
+    return max(1, n), desc
+
+
 def cpu_baseline(opt):
     """Hot path of ONE sample of the workload (1/6 of a batch) through the C oracle, all host threads."""
     import numpy as np
@@ -93,7 +120,7 @@ def cpu_baseline(opt):
     # figure of this object, as in earlier rounds.  ALL cores beside it: the oracle's loops run over (sample, plane,
     # row) with thread-private accumulators (no atomics), so one sample scales; the thread count that ran fastest of
     # {every hardware thread, half of them (one per core where SMT is on)} is reported with its count.
-    ncpu = os.cpu_count() or 1
+    ncpu, quota = usable_cpus()
     oracle.set_num_threads(1)
     dt1, n1 = timed(12.0, 8)
     best = None
@@ -110,11 +137,11 @@ def cpu_baseline(opt):
            "sample": "1 sample (1/6 batch) of config 2: 2x cost volume fwd+bwd (48x160, D=%d, C=32->G=%d), 12x "
                      "warp+SSIM/L1 fwd+bwd at %dx%d, identity + smoothness losses; C oracle (a port of the reference's "
                      "CPU path, not the product), %d runs of %.2f s on 1 thread (what the reference's trainer.py:2-4 forces; "
-                     "%d hardware threads on this box)" % (D, G, H, W, n1, dt1, ncpu)}
+                     "%d hardware threads on this box, %s)" % (D, G, H, W, n1, dt1, os.cpu_count() or 0, quota)}
     if best is not None:
         res["all_cores"] = {"value": 1.0 / best[0], "unit": "images/s (hot path only, no conv nets)", "cores": best[2],
                             "ms_per_image": 1e3 * best[0], "speedup_over_1_thread": dt1 / best[0],
-                            "sample": "the same sample, %d runs of %.3f s with %d OpenMP threads" % (best[1], best[0], best[2])}
+                            "sample": "the same sample, %d runs of %.3f s with %d OpenMP threads (%s)" % (best[1], best[0], best[2], quota)}
     return res
 
 
@@ -306,6 +333,12 @@ def main():
     # separate dispatches); the Python-side figure (argument checks, workspace, finish kernel, launch gaps) is kept beside it
     entry_us = {k_: times[k_]["avg_us"] for k_ in CONV_KERNELS if k_ in times}
     times.update(ops.library_kernel_times_us(CONV_KERNELS))
+    # the photometric / smoothness kernels inside the step (all dispatches of an entry point together: forward = main + finish
+    # kernels, backward = main + finish + up-sampling adjoint): kernel time per step and the slowest single dispatch
+    photo_in_step = {}
+    for k_, v_ in ops.library_kernel_times_us([n_ for n_ in HOT_PATH_ENTRY_POINTS if not n_.startswith("md_costvol")]).items():
+        photo_in_step[k_] = {"us_per_step": sum(v_["all_us"]) / a.steps, "dispatches_per_step": v_["launches"] / a.steps,
+                             "max_dispatch_us": max(v_["all_us"])}
     if os.environ.get("MD_BENCH_DUMP_TIMES"):
         for k_ in ("md_costvol_fwd" + sfx, "md_costvol_bwd" + sfx, wild):
             print(k_, " ".join("%.0f" % t for t in times.get(k_, {}).get("all_us", [])), file=sys.stderr)
@@ -369,6 +402,8 @@ def main():
             conv[name] = e
         if conv:
             out["reg3d_handoff_kernels"] = conv
+        if photo_in_step:
+            out["photometric_kernels_in_step"] = photo_in_step
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(opt)
             if not a.trainer_args:

@@ -843,7 +843,10 @@ int launch_cl(const CvPtrs &q, CvDims dm, hipStream_t stream) {
     const int N = dm.C / dm.G, LPP = dm.G / 4, TW = 64 / LPP;
     // waves per workgroup: forward 8 (16 x 8 pixel tile), backward 4 (its LDS is 3x the source window per workgroup; measured at
     // B=6, 48x160, D=96: backward 131 us with 4 against 152 with 8, forward 68 against 62).  Only these two are instantiated.
-    constexpr int NW = BWD ? 4 : 8;
+#ifndef MD_CL_FWD_NW
+#define MD_CL_FWD_NW 8
+#endif
+    constexpr int NW = BWD ? 4 : MD_CL_FWD_NW;
     dm.tiles_x = md_cdiv(dm.w, TW);
     dm.tiles = dm.tiles_x * md_cdiv(dm.h, NW);
     dm.splits = 1;
