@@ -336,7 +336,8 @@ def main():
     # the photometric / smoothness kernels inside the step (all dispatches of an entry point together: forward = main + finish
     # kernels, backward = main + finish + up-sampling adjoint): kernel time per step and the slowest single dispatch
     photo_in_step = {}
-    for k_, v_ in ops.library_kernel_times_us([n_ for n_ in HOT_PATH_ENTRY_POINTS if not n_.startswith("md_costvol")]).items():
+    for k_, v_ in ops.library_kernel_times_us([n_ for n_ in HOT_PATH_ENTRY_POINTS if not n_.startswith("md_costvol")] +
+                                              ["md_bn_stats", "md_bn_apply", "md_bn_bwd_reduce", "md_bn_bwd_dx"]).items():
         photo_in_step[k_] = {"us_per_step": sum(v_["all_us"]) / a.steps, "dispatches_per_step": v_["launches"] / a.steps,
                              "max_dispatch_us": max(v_["all_us"])}
     if os.environ.get("MD_BENCH_DUMP_TIMES"):

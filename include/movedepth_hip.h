@@ -286,6 +286,33 @@ int md_conv3d_c16_bwd_weight(const float *x, int x_planar, const float *gy, floa
                              long long dw_stride_ci, long long dw_stride_k, void *ws, size_t ws_bytes, int B, int Ci, int Co,
                              int D, int H, int W, md_stream_t stream);
 
+/* ---- BatchNorm with synchronised statistics, every normalisation layer of the model ------------------------------------
+ * The reference's data-parallel path (trainer.py:69-135, train_movedepth.sh:15 --ddp) converts every BatchNorm2d / BatchNorm3d
+ * to torch.nn.SyncBatchNorm: batch statistics over the GLOBAL batch.  These five entry points are that layer for a
+ * channels-last tensor x[row * C + c] (torch.channels_last, channels_last_3d, or an (N, C) matrix; C a multiple of 4 up to
+ * 4096; rows = N * spatial size), one launch each, deterministic reductions:
+ *   md_bn_stats       sums[0:C] = sum x, sums[C:2C] = sum x^2, in DOUBLE  -> the caller all-reduces the 2C sums over the ranks
+ *   md_bn_apply       mean / biased variance from the (global) sums and n_total rows; y = (x - mean) * invstd * gamma + beta,
+ *                     relu != 0: followed by max(0, .); writes stat[0:C] = mean, stat[C:2C] = invstd for the backward and
+ *                     updates running_mean / running_var (unbiased variance, `momentum`; either may be NULL)
+ *   md_bn_eval        evaluation mode: the running statistics instead
+ *   md_bn_bwd_reduce  sums[0:C] = sum dz (= dbeta), sums[C:2C] = sum dz * xhat (= dgamma), dz = dy * [z > 0] when relu
+ *                     -> the caller all-reduces a copy of the 2C sums
+ *   md_bn_bwd_dx      dx = gamma * invstd * (dz - sums[0:C] / n_total - xhat * sums[C:2C] / n_total)
+ * ws: md_bn_ws_bytes() bytes, ZEROED ONCE by the caller and then reused (the reduction kernels leave it zeroed); one
+ * workspace per stream. */
+size_t md_bn_ws_bytes(void);
+int md_bn_stats(const float *x, long long nrows, int C, double *sums, void *ws, md_stream_t stream);
+int md_bn_apply(const float *x, const double *sums, long long n_total, float eps, float momentum, const float *gamma,
+                const float *beta, int relu, float *running_mean, float *running_var, float *stat, float *y, long long nrows,
+                int C, md_stream_t stream);
+int md_bn_eval(const float *x, const float *running_mean, const float *running_var, float eps, const float *gamma,
+               const float *beta, int relu, float *y, long long nrows, int C, md_stream_t stream);
+int md_bn_bwd_reduce(const float *dy, const float *x, const float *stat, const float *gamma, const float *beta, int relu,
+                     long long nrows, int C, float *sums, void *ws, md_stream_t stream);
+int md_bn_bwd_dx(const float *dy, const float *x, const float *stat, const float *gamma, const float *beta, int relu,
+                 const float *sums, long long n_total, long long nrows, int C, float *dx, md_stream_t stream);
+
 /* ---- training-mode BatchNorm + ReLU (+ residual) of the regulariser's two full-resolution layers -------------
  * conv0's BatchNorm3d + ReLU (networks/resnet_encoder.py:231 through ConvBnReLU3D) and conv11's BatchNorm3d + ReLU
  * followed by `x = conv0 + self.conv11(x)` (:249-252, :264).  x, y, res, dy, dx: channels-last volumes flattened to

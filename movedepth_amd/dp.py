@@ -89,5 +89,10 @@ def broadcast_parameters(modules, src=0, process_group=None):
     for m in modules:
         for t in list(m.parameters()) + list(m.buffers()):
             if t.device.type == "cpu" and dist.get_backend(process_group) == "nccl":
-                continue  # host-resident BatchNorm counters (--bn_counter_on_host): identical on every rank at start
+                # host-resident BatchNorm counters (--bn_counter_on_host): RCCL moves device memory only, so they travel through
+                # a device copy -- rank 0's value wins, also after a load_model() that only it performed
+                tmp = t.data.to(torch.device("cuda", torch.cuda.current_device()))
+                dist.broadcast(tmp, src=src, group=process_group)
+                t.data.copy_(tmp)
+                continue
             dist.broadcast(t.data, src=src, group=process_group)

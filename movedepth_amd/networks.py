@@ -17,6 +17,12 @@ import torch.nn.functional as F
 from . import ops
 
 
+def _bn_act(bn, relu, x):
+    """relu(bn(x)) -- one kernel when `bn` is a HipSyncBatchNorm that carries the ReLU (convert_hip_sync_batchnorm)"""
+    y = bn(x)
+    return y if getattr(bn, "relu", False) else relu(y)
+
+
 # --------------------------------------------------------------------------- ResNet (torchvision-compatible keys)
 class _BasicBlock(nn.Module):
     expansion = 1
@@ -32,7 +38,7 @@ class _BasicBlock(nn.Module):
 
     def forward(self, x):
         idt = x if self.downsample is None else self.downsample(x)
-        y = self.relu(self.bn1(self.conv1(x)))
+        y = _bn_act(self.bn1, self.relu, self.conv1(x))
         y = self.bn2(self.conv2(y))
         return self.relu(y + idt)
 
@@ -53,8 +59,8 @@ class _Bottleneck(nn.Module):
 
     def forward(self, x):
         idt = x if self.downsample is None else self.downsample(x)
-        y = self.relu(self.bn1(self.conv1(x)))
-        y = self.relu(self.bn2(self.conv2(y)))
+        y = _bn_act(self.bn1, self.relu, self.conv1(x))
+        y = _bn_act(self.bn2, self.relu, self.conv2(y))
         y = self.bn3(self.conv3(y))
         return self.relu(y + idt)
 
@@ -124,7 +130,7 @@ class ResnetEncoder(nn.Module):
     def forward(self, input_image):
         e = self.encoder
         x = (input_image - 0.45) / 0.225
-        f0 = e.relu(e.bn1(e.conv1(x)))
+        f0 = _bn_act(e.bn1, e.relu, e.conv1(x))
         f1 = e.layer1(e.maxpool(f0))
         f2 = e.layer2(f1)
         f3 = e.layer3(f2)
@@ -246,6 +252,8 @@ class Conv2d(nn.Module):
         x = self.conv(x)
         if self.bn is not None:
             x = self.bn(x)
+            if self.relu and getattr(self.bn, "relu", False):   # HipSyncBatchNorm carrying the ReLU
+                return x
         return F.relu(x, inplace=True) if self.relu else x
 
 
@@ -305,7 +313,8 @@ class ConvBnReLU3D(nn.Module):
 
     def forward(self, x):
         y = self.bn(self.conv(x))
-        return y if isinstance(self.bn, FusedBNReLU3d) else F.relu(y, inplace=True)   # the fused module includes the ReLU
+        # the fused modules include the ReLU
+        return y if (isinstance(self.bn, FusedBNReLU3d) or getattr(self.bn, "relu", False)) else F.relu(y, inplace=True)
 
 
 class FusedBNReLU3d(nn.Module):
@@ -337,6 +346,90 @@ class FusedBNReLU3d(nn.Module):
         y = F.relu(F.batch_norm(x, self.running_mean, self.running_var, self.weight, self.bias, self.training, self.momentum,
                                 self.eps))
         return y if res is None else y + res
+
+
+class HipSyncBatchNorm(nn.Module):
+    """BatchNorm2d / BatchNorm3d with statistics over the global batch of `sync_group` (torch.nn.SyncBatchNorm's semantics; the
+    reference's --ddp path converts every BatchNorm to it, trainer.py:69-135) on the hand-written kernels of csrc/syncbn.hip:
+    one all-reduce of 2C sums per layer and direction.  Parameter / buffer names are BatchNorm's, so checkpoints are
+    interchangeable.  Not a _BatchNorm subclass on purpose (torch's SyncBatchNorm conversion must skip it).  `relu`: the ReLU
+    that follows the layer, fused (the caller then skips its own).  In evaluation mode, or where the kernels do not apply
+    (CPU tensors, channel counts that are not multiples of 4), it is F.batch_norm -- without synchronisation, so training
+    such a layer under a group raises."""
+
+    def __init__(self, num_features, eps=1e-5, momentum=0.1, relu=False):
+        super().__init__()
+        self.num_features, self.eps, self.momentum, self.relu = num_features, eps, momentum, relu
+        self.weight = nn.Parameter(torch.ones(num_features))
+        self.bias = nn.Parameter(torch.zeros(num_features))
+        self.register_buffer("running_mean", torch.zeros(num_features))
+        self.register_buffer("running_var", torch.ones(num_features))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+        self.sync_group = None
+
+    @classmethod
+    def from_batchnorm(cls, bn, group=None):
+        m = cls(bn.num_features, bn.eps, 0.1 if bn.momentum is None else bn.momentum)
+        if bn.affine:
+            with torch.no_grad():
+                m.weight.copy_(bn.weight)
+                m.bias.copy_(bn.bias)
+            m.weight.requires_grad_(bn.weight.requires_grad)
+            m.bias.requires_grad_(bn.bias.requires_grad)
+        m.running_mean, m.running_var, m.num_batches_tracked = bn.running_mean, bn.running_var, bn.num_batches_tracked
+        m.sync_group = group
+        m.train(bn.training)
+        return m.to(bn.weight.device if bn.affine else bn.running_mean.device)
+
+    def forward(self, x):
+        if self.training:
+            self.num_batches_tracked.add_(1)
+            if ops.sync_batch_norm_supported(x):
+                return ops._SyncBatchNorm.apply(x, self.weight, self.bias, self.running_mean, self.running_var, self.momentum, self.eps,
+                                                int(self.relu), self.sync_group)
+            if self.sync_group is not None:
+                raise RuntimeError("HipSyncBatchNorm: synchronised statistics need a GPU tensor with a multiple of 4 channels, got %s %s"
+                                   % (x.device, tuple(x.shape)))
+        y = F.batch_norm(x, self.running_mean, self.running_var, self.weight, self.bias, self.training, self.momentum, self.eps)
+        return F.relu(y) if self.relu else y
+
+
+def convert_hip_sync_batchnorm(module, group=None, fuse_relu=True):
+    """Every BatchNorm2d / BatchNorm3d below `module` -> HipSyncBatchNorm sharing its parameters and buffers (what
+    torch.nn.SyncBatchNorm.convert_sync_batchnorm does for torch's layer).  FusedBNReLU3d layers keep their own kernels and get
+    `group` as their sync_group."""
+    if isinstance(module, torch.nn.modules.batchnorm._BatchNorm) and not isinstance(module, nn.BatchNorm1d) and \
+            module.track_running_stats and module.num_features % 4 == 0:
+        return HipSyncBatchNorm.from_batchnorm(module, group)
+    if isinstance(module, FusedBNReLU3d):
+        module.sync_group = group
+        return module
+    for name, child in list(module.named_children()):
+        new = convert_hip_sync_batchnorm(child, group, fuse_relu)
+        if new is not child:
+            setattr(module, name, new)
+    if not fuse_relu:
+        return module
+    # the ReLU that follows a normalisation moves into its kernels (one launch fewer each way, and no separate pass over the tensor)
+    # wherever the containing module is one of ours and calls the ReLU right after the layer
+    hip = lambda m: isinstance(m, HipSyncBatchNorm)
+    if isinstance(module, (_BasicBlock, _ResNetTrunk)) and hip(module.bn1):
+        module.bn1.relu = True
+    elif isinstance(module, _Bottleneck):
+        for bn in (module.bn1, module.bn2):
+            if hip(bn):
+                bn.relu = True
+    elif isinstance(module, Conv2d) and module.relu and hip(module.bn):
+        module.bn.relu = True
+    elif isinstance(module, ConvBnReLU3D) and hip(module.bn):
+        module.bn.relu = True
+    elif isinstance(module, nn.Sequential):
+        kids = list(module.named_children())
+        for (n0, m0), (n1, m1) in zip(kids, kids[1:]):
+            if hip(m0) and isinstance(m1, nn.ReLU):
+                m0.relu = True
+                setattr(module, n1, nn.Identity())   # no parameters: the state_dict keeps its keys
+    return module
 
 
 def _up3d(cin, cout, k=3, pad=1, opad=1, stride=2):

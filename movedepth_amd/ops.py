@@ -978,6 +978,141 @@ def bn_relu_3d(x, weight, bias, res=None, running_mean=None, running_var=None, m
     return _BnRelu3d.apply(x.float(), weight, bias, res, running_mean, running_var, float(momentum), float(eps), group)
 
 
+# --------------------------------------------------------------------------- BatchNorm with synchronised statistics
+# The model calls this 115 times per step and direction and the step is nearly host-bound (kernel time ~ wall time): everything
+# below is written for few Python operations per call -- raw pointers as ints (ctypes converts them by the argtypes), one
+# allocation for the per-call scalars, no dtype / layout conversions when the tensor already is what the kernels read.
+_BN_WS = {}
+_BN_FN = None
+_CL_FORMAT = {4: torch.channels_last, 5: torch.channels_last_3d}
+
+
+def _bn_fns():
+    global _BN_FN
+    if _BN_FN is None:
+        lib = _lib.load()
+        _BN_FN = (lib.md_bn_stats, lib.md_bn_apply, lib.md_bn_bwd_reduce, lib.md_bn_bwd_dx)
+    return _BN_FN
+
+
+def _bn_ws(device, stream):
+    """The reduction kernels' workspace: zeroed once, left zeroed by every launch (one per device and stream) -> raw pointer"""
+    key = (device.index, stream)
+    ws = _BN_WS.get(key)
+    if ws is None:
+        t = torch.zeros(int(_lib.load().md_bn_ws_bytes()), dtype=torch.uint8, device=device)
+        ws = _BN_WS[key] = (t, t.data_ptr())
+    return ws[1]
+
+
+def _rows_channels_last(x):
+    """x (N,C,*spatial) -> (float32 tensor stored channels-last, rows, C); a copy only if it is not stored that way already"""
+    if x.dtype is not torch.float32:
+        x = x.float()
+    nd = x.dim()
+    if nd == 2:
+        if not x.is_contiguous():
+            x = x.contiguous()
+    else:
+        fmt = _CL_FORMAT.get(nd)
+        if fmt is None:
+            raise _lib.MovedepthHipError("sync_batch_norm: %d-D input unsupported (2-D, 4-D or 5-D)" % nd)
+        if not x.is_contiguous(memory_format=fmt):
+            x = x.contiguous(memory_format=fmt)
+    C = x.shape[1]
+    return x, x.numel() // C, C
+
+
+def _f32c(t):
+    return t if (t.dtype is torch.float32 and t.is_contiguous()) else t.float().contiguous()
+
+
+class _SyncBatchNorm(torch.autograd.Function):
+    """Training-mode batch normalisation over the global batch of a process group (csrc/syncbn.hip): statistics -> ONE all-reduce
+    of 2C doubles -> apply, and in the backward two sums -> ONE all-reduce of 2C floats -> dx.  group None: this process only."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, relu, group):
+        x, rows, C = _rows_channels_last(x)
+        dev = x.device
+        stream = torch._C._cuda_getCurrentRawStream(dev.index)
+        f_stats, f_apply, _, _ = _bn_fns()
+        # one allocation: 2C doubles (the sums) followed by 2C floats (mean, invstd for the backward)
+        buf = torch.empty(3 * C, device=dev, dtype=torch.float64)
+        sums = buf[:2 * C]
+        stat = buf[2 * C:].view(torch.float32)
+        rc = f_stats(x.data_ptr(), rows, C, sums.data_ptr(), _bn_ws(dev, stream), stream)
+        if rc:
+            _lib.check(rc, "md_bn_stats")
+        n_total = rows
+        if group is not None:
+            import torch.distributed as dist
+            # every rank contributes the same number of rows (the per-GPU batch is fixed: the loaders drop the last batch)
+            dist.all_reduce(sums, group=group)
+            n_total = rows * dist.get_world_size(group)
+        y = torch.empty_like(x)   # preserves the channels-last strides
+        w, b = _f32c(weight), _f32c(bias)
+        rm = running_mean.data_ptr() if (running_mean is not None and running_mean.dtype is torch.float32) else None
+        rv = running_var.data_ptr() if (running_var is not None and running_var.dtype is torch.float32) else None
+        rc = f_apply(x.data_ptr(), sums.data_ptr(), n_total, eps, momentum, w.data_ptr(), b.data_ptr(), relu, rm, rv, stat.data_ptr(),
+                     y.data_ptr(), rows, C, stream)
+        if rc:
+            _lib.check(rc, "md_bn_apply")
+        ctx.save_for_backward(x, stat, w, b)
+        ctx.group, ctx.relu = group, relu
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, stat, w, b = ctx.saved_tensors
+        dy, rows, C = _rows_channels_last(dy)
+        dev = x.device
+        stream = torch._C._cuda_getCurrentRawStream(dev.index)
+        _, _, f_reduce, f_dx = _bn_fns()
+        sums = torch.empty(2 * C, device=dev, dtype=torch.float32)
+        rc = f_reduce(dy.data_ptr(), x.data_ptr(), stat.data_ptr(), w.data_ptr(), b.data_ptr(), ctx.relu, rows, C, sums.data_ptr(),
+                      _bn_ws(dev, stream), stream)
+        if rc:
+            _lib.check(rc, "md_bn_bwd_reduce")
+        d_beta, d_gamma = sums[:C], sums[C:]          # this rank's sums (the gradient reducer averages parameter gradients)
+        n_total = rows
+        if ctx.group is not None:
+            import torch.distributed as dist
+            sums = sums.clone()
+            dist.all_reduce(sums, group=ctx.group)
+            n_total = rows * dist.get_world_size(ctx.group)
+        dx = torch.empty_like(x)
+        rc = f_dx(dy.data_ptr(), x.data_ptr(), stat.data_ptr(), w.data_ptr(), b.data_ptr(), ctx.relu, sums.data_ptr(), n_total, rows, C,
+                  dx.data_ptr(), stream)
+        if rc:
+            _lib.check(rc, "md_bn_bwd_dx")
+        return dx, d_gamma, d_beta, None, None, None, None, None, None
+
+
+def sync_batch_norm_supported(x):
+    return x.is_cuda and x.dim() in (2, 4, 5) and x.shape[1] % 4 == 0 and 4 <= x.shape[1] <= 4096 and \
+        (256 % (x.shape[1] // 4) == 0 or x.shape[1] // 4 <= 1024)
+
+
+def sync_batch_norm(x, weight, bias, running_mean=None, running_var=None, momentum=0.1, eps=1e-5, relu=False, group=None):
+    """F.batch_norm(training=True) [+ ReLU] with the statistics taken over `group`'s global batch (torch.nn.SyncBatchNorm,
+    which the reference's --ddp path converts every BatchNorm to: trainer.py:69-135).  x: (N,C,*spatial) on the GPU; the
+    result is stored channels-last.  Running statistics are updated in place."""
+    if not sync_batch_norm_supported(x):
+        raise _lib.MovedepthHipError("sync_batch_norm: needs a GPU tensor (N,C,...) with C a multiple of 4 <= 4096, got %s %s" % (x.device, tuple(x.shape)))
+    return _SyncBatchNorm.apply(x, weight, bias, running_mean, running_var, float(momentum), float(eps), int(bool(relu)), group)
+
+
+def batch_norm_eval(x, weight, bias, running_mean, running_var, eps=1e-5, relu=False):
+    """evaluation-mode BatchNorm [+ ReLU] from the running statistics, one kernel; no gradient"""
+    with torch.no_grad():
+        x, rows, C = _rows_channels_last(x.float())
+        y = torch.empty_like(x)
+        _lib.call("md_bn_eval", _p(x), _p(running_mean.float()), _p(running_var.float()), float(eps), _p(weight.float().contiguous()),
+                  _p(bias.float().contiguous()), int(relu), _p(y), rows, C, _stream())
+    return y
+
+
 # --------------------------------------------------------------------------- pose parameters -> 4x4
 class _PoseMatrix(torch.autograd.Function):
     @staticmethod

@@ -112,6 +112,11 @@ class MonodepthOptions:
                             "headline bench is fp32")
         p.add_argument("--fused_adam", type=int, default=1, help="torch's fused Adam kernel on the GPU (0: default implementation)")
         p.add_argument("--sync_bn", type=int, default=1, help="with --ddp: convert BatchNorm to SyncBatchNorm (reference)")
+        p.add_argument("--sync_bn_impl", default="hip", choices=["hip", "torch"],
+                       help="synchronised BatchNorm on the hand-written kernels (networks.HipSyncBatchNorm: one all-reduce of 2C "
+                            "sums per layer and direction) or torch.nn.SyncBatchNorm (torch's native batch-norm kernels)")
+        p.add_argument("--force_sync_bn", type=int, default=0,
+                       help="measurement: run the synchronised-BatchNorm path of --sync_bn_impl without --ddp (a group of one)")
         p.add_argument("--grad_bucket_mb", type=float, default=32.0, help="with --ddp: all-reduce bucket size")
         self.parser = p
 

@@ -103,8 +103,15 @@ class Trainer:
         if opt.vol_layout != "auto":
             self.vol_layout = opt.vol_layout
         for k, m in self.models.items():
-            if opt.ddp and opt.sync_bn:   # also with MD_SHARE_GPU=1: SyncBatchNorm runs over gloo on CUDA tensors
-                m = torch.nn.SyncBatchNorm.convert_sync_batchnorm(m)
+            if opt.sync_bn and (opt.ddp or opt.force_sync_bn):   # also with MD_SHARE_GPU=1: over gloo on CUDA tensors
+                if opt.sync_bn_impl == "hip":
+                    # every BatchNorm on the kernels of csrc/syncbn.hip: statistics over the global batch, one all-reduce of 2C
+                    # sums per layer and direction (torch's SyncBatchNorm is built from its native batch-norm kernels, which
+                    # cost a rank 14 % of a step before any collective: DESIGN 6)
+                    m = networks.convert_hip_sync_batchnorm(m, dist.group.WORLD if opt.ddp else None,
+                                                            fuse_relu=os.environ.get("MD_HIPBN_FUSE_RELU", "1") == "1")
+                elif opt.ddp:
+                    m = torch.nn.SyncBatchNorm.convert_sync_batchnorm(m)
             self.models[k] = m.to(self.device)
             if opt.nets2d_channels_last and k != "reg3d" and k not in opt.nets2d_channels_last_skip.split(","):
                 # 2-D networks in channels_last: same results (outputs equal to 1e-7, tests/test_trainer_parity.py), the
@@ -120,7 +127,7 @@ class Trainer:
             # nothing on the device reads (momentum is fixed): keep the counters in host memory.  Same state_dict.
             for m in self.models.values():
                 for mod in m.modules():
-                    if isinstance(mod, (torch.nn.modules.batchnorm._BatchNorm, networks.FusedBNReLU3d)) and \
+                    if isinstance(mod, (torch.nn.modules.batchnorm._BatchNorm, networks.FusedBNReLU3d, networks.HipSyncBatchNorm)) and \
                             mod.num_batches_tracked is not None:
                         mod.num_batches_tracked = mod.num_batches_tracked.cpu()
         for k in main:

@@ -10,7 +10,7 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 STEPS=${STEPS:-10}; WARM=${WARM:-3}
 rm -rf /tmp/prof_step
-rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_step -o s -- python $ROOT/bench.py --steps $STEPS --warmup $WARM --no_cpu_baseline > /tmp/prof_step.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_step -o s -- python $ROOT/bench.py --steps $STEPS --warmup $WARM --no_cpu_baseline --trainer_args="${TRAINER_ARGS:-}" > /tmp/prof_step.log 2>&1
 tail -1 /tmp/prof_step.log | cut -c1-300
 python - <<PY
 import csv, json, collections
@@ -37,7 +37,7 @@ cat = {"library 3-D conv (CK)": ("ck::", "_ZN2ck", "naive_conv"), "library 2-D c
        "BatchNorm (library)": ("BatchNorm", "batch_norm"),
        "elementwise / copy / transpose / fill / optimizer (torch, MIOpen)": ("elementwise", "transpose", "fillBuffer", "SubTensor", "copyBuffer", "CatArray", "reduce_kernel", "upsample", "reflection_pad", "index", "multi_tensor", "fused_adam", "distribution", "OpTensor"),
        "hand-written: cost volume": ("costvol", "cl_fwd_kernel", "cl_bwd_kernel"), "hand-written: reg3d first/last conv": ("conv3d_c",),
-       "hand-written: fused BatchNorm+ReLU": ("bn_",),
+       "hand-written: BatchNorm (fused BatchNorm+ReLU of reg3d; synchronised BatchNorm)": ("bn_",),
        "hand-written: photometric + post-volume": ("photo_", "up_adjoint", "warp_", "ssim_", "reproj_", "masked_min", "smooth_", "sel_", "sel4_", "schedule_", "fuse_", "disp_up", "convex", "backproject", "project3d", "pose_")}
 acc = {k: 0.0 for k in cat}; other = 0.0
 mine = tuple(p for k, v in cat.items() if k.startswith("hand-written") for p in v)
