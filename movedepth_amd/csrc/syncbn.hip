@@ -42,11 +42,14 @@ __host__ inline bool bn_geo(long long nrows, int C, BnGeo &g) {
     else return false;
     if (g.NT > 1024) return false;
     g.npieces = nrows * g.QN;
-    g.NTR = g.NT;
-    if (g.npieces >= (1 << 18) && 1024 % g.QN == 0) g.NTR = 1024;
+    // Reductions: 1024 threads per block wherever the quads divide it -- the finishing block reads nblk * 2C partial sums past
+    // every cache (~1.5 us per batch of eight loads per thread), so few fat blocks: at most 16384 / C of them (512 channels: 32
+    // blocks = two batches per thread), each streaming with 16 waves
+    g.NTR = (1024 % g.QN == 0 && g.npieces >= 4096) ? 1024 : g.NT;
     long long want = (g.npieces + (long long)g.NTR * 8 - 1) / ((long long)g.NTR * 8);   // >= 8 pieces per thread
-    long long cap = BN_MAX_PARTIAL_FLOATS / (2 * C);
-    if (cap < 8) cap = 8;
+    long long cap = 16384 / C;
+    if (cap < 16) cap = 16;
+    if (cap * 2 * C > BN_MAX_PARTIAL_FLOATS + 2 * 4096 * 8) cap = (BN_MAX_PARTIAL_FLOATS + 2 * 4096 * 8) / (2 * C);
     if (cap > 1024) cap = 1024;
     if (want < 1) want = 1;
     g.nblk = (int)(want < cap ? want : cap);
@@ -68,8 +71,22 @@ __device__ __forceinline__ void bn_block_finish(float4 a, float4 b, int QN, floa
     extern __shared__ float4 sh[];   // [2][NT]
     __shared__ bool last;
     const int NT = blockDim.x, tid = threadIdx.x, C = 4 * QN;
-    sh[tid] = a;
-    sh[NT + tid] = b;
+    int nper = NT / QN;   // values per quad handed to the serial sum below
+    if ((QN & (QN - 1)) == 0 && QN <= 32) {
+        // few quads (8 ... 128 channels): the lanes of a wave that share a quad meet by shuffles first (a fixed tree), so that the
+        // serial sum below adds one value per wave instead of NT / QN of them -- with 8 channels and 1024 threads that loop was
+        // 512 dependent LDS reads by two threads, 20 us of a 39 us launch
+        for (int o = QN; o < 64; o <<= 1) {
+            a.x += __shfl_xor(a.x, o, 64); a.y += __shfl_xor(a.y, o, 64); a.z += __shfl_xor(a.z, o, 64); a.w += __shfl_xor(a.w, o, 64);
+            b.x += __shfl_xor(b.x, o, 64); b.y += __shfl_xor(b.y, o, 64); b.z += __shfl_xor(b.z, o, 64); b.w += __shfl_xor(b.w, o, 64);
+        }
+        const int lane = tid & 63, wave = tid >> 6;
+        nper = NT >> 6;
+        if (lane < QN) { sh[wave * QN + lane] = a; sh[NT + wave * QN + lane] = b; }
+    } else {
+        sh[tid] = a;
+        sh[NT + tid] = b;
+    }
     __syncthreads();
     // The partial sums travel between workgroups -- possibly on different XCDs, whose L2 caches are not coherent with each other
     // -- as RELAXED AGENT-SCOPE ATOMIC stores / loads: they are performed at the device's coherence point, past the L2.  What a
@@ -78,7 +95,7 @@ __device__ __forceinline__ void bn_block_finish(float4 a, float4 b, int QN, floa
     // (acknowledged: s_waitcnt vmcnt(0)) before its thread 0 takes the ticket, and the ticket is an atomic at the same scope.
     if (tid < QN) {   // fixed order within the block
         float4 sa = sh[tid], sb = sh[NT + tid];
-        for (int k = tid + QN; k < NT; k += QN) { sa = f4add(sa, sh[k]); sb = f4add(sb, sh[NT + k]); }
+        for (int k = 1; k < nper; ++k) { sa = f4add(sa, sh[k * QN + tid]); sb = f4add(sb, sh[NT + k * QN + tid]); }
         float *pa = partial + (size_t)blockIdx.x * 2 * C;
         const float va[4] = {sa.x, sa.y, sa.z, sa.w}, vb[4] = {sb.x, sb.y, sb.z, sb.w};
 #pragma unroll
