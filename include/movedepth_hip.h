@@ -355,7 +355,10 @@ int md_project3d(const float *points, const float *K, const float *T, int Bs, in
                  float *pix, md_stream_t stream);
 
 /* ---- per-kernel timing (measurement only; not part of the reference's interface) ---------------------------------
- * md_kernel_timing_enable(1) makes the plane-sweep and md_conv3d_* entry points attach a HIP start / stop event pair to their (main) KERNEL dispatch
+ * md_kernel_timing_enable(mask): classes of entry points to time -- 2 = plane sweep + md_conv3d_*, 4 = photometric / smoothness / packing,
+ * 8 = md_bn_*; 1 = all of them; 0 = off (drops the records).  A timed dispatch costs its stream about 5 us (completion signal with timestamps, two
+ * events): 444 timed BatchNorm launches per training step read as +2.6 ms of step time, so bench.py times class 8 only on request.
+ * A timed entry point attaches a HIP start / stop event pair to its (main) KERNEL dispatch
  * (hipExtLaunchKernelGGL: the dispatch's own begin / end timestamps, on the launch stream; not the argument checks or memsets); md_kernel_timing_enable(0) stops and drops the records.
  * md_kernel_timing_read(name, ...) synchronises the recorded events of entry point `name` ("md_costvol_fwd",
  * "md_costvol_bwd", with _bf16 / _f16 suffixes) and returns their average / minimum duration in microseconds and their

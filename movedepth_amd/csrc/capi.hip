@@ -19,7 +19,7 @@ extern "C" int md_abi_version(void) { return 13; }
 #include <vector>
 namespace {
 struct TimingRec { const char *name; hipEvent_t a, b; };
-bool g_timing = false;
+int g_timing = 0;   // bit mask of kernel classes, md_kernel_timing_enable
 std::vector<TimingRec> g_recs;
 }  // namespace
 
@@ -44,6 +44,10 @@ extern "C" int md_costvol_stats(int enable, unsigned long long *out8) {
 void md_timing_pair(const char *name, hipEvent_t *start, hipEvent_t *stop) {
     *start = *stop = nullptr;
     if (!g_timing) return;
+    // classes (a timed dispatch costs the stream ~5 us: time only what is asked for): 2 = plane sweep + md_conv3d_*,
+    // 4 = photometric / smoothness / packing, 8 = md_bn_*
+    const int cls = strncmp(name, "md_bn_", 6) == 0 ? 8 : (strncmp(name, "md_costvol", 10) == 0 || strncmp(name, "md_conv3d", 9) == 0) ? 2 : 4;
+    if (!(g_timing & cls)) return;
     TimingRec r{name, nullptr, nullptr};
     if (hipEventCreate(&r.a) != hipSuccess) return;
     if (hipEventCreate(&r.b) != hipSuccess) { (void)hipEventDestroy(r.a); return; }
@@ -54,7 +58,7 @@ void md_timing_pair(const char *name, hipEvent_t *start, hipEvent_t *stop) {
 extern "C" int md_kernel_timing_enable(int on) {
     for (auto &r : g_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     g_recs.clear();
-    g_timing = on != 0;
+    g_timing = on == 1 ? 14 : on;   // 1 = every class, otherwise the mask of classes (md_timing_pair)
     return MD_OK;
 }
 extern "C" int md_kernel_timing_list(const char *name, double *us, int cap) {

@@ -22,9 +22,13 @@ def enable_kernel_timing(names):
     KERNEL_EVENTS = {n: [] for n in names}
 
 
+TIME_ROOFLINE, TIME_PHOTOMETRIC, TIME_BATCHNORM = 2, 4, 8   # classes of md_kernel_timing_enable (include/movedepth_hip.h)
+
+
 def enable_library_kernel_timing(on=True):
-    """HIP events recorded INSIDE the library, directly around the plane-sweep kernel launches (md_kernel_timing_*)."""
-    _lib.call("md_kernel_timing_enable", int(bool(on)))
+    """HIP events recorded INSIDE the library, directly around its kernel launches (md_kernel_timing_*).  True: every class;
+    an int: a mask of TIME_* classes (a timed dispatch costs its stream ~5 us, so a training step times only what it reports)."""
+    _lib.call("md_kernel_timing_enable", int(on))
 
 
 def library_kernel_times_us(names):
