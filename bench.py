@@ -340,14 +340,15 @@ def main():
     # the photometric / smoothness kernels inside the step (all dispatches of an entry point together: forward = main + finish
     # kernels, backward = main + finish + up-sampling adjoint): kernel time per step and the slowest single dispatch
     photo_in_step = {}
-    PHOTO_STEPS = 10
+    PHOTO_STEPS = int(os.environ.get("MD_BENCH_PHOTO_STEPS", "10"))   # 0 under tools/profile_step.sh, which counts the steps in the trace
     ops.enable_library_kernel_timing(ops.TIME_PHOTOMETRIC | ops.TIME_BATCHNORM)   # (drops the records read above)
     for _ in range(PHOTO_STEPS):
         trainer.train_step(dict(inputs))
     torch.cuda.synchronize()
     for k_, v_ in ops.library_kernel_times_us([n_ for n_ in HOT_PATH_ENTRY_POINTS if not n_.startswith("md_costvol")] +
                                               ["md_bn_stats", "md_bn_apply", "md_bn_bwd_reduce", "md_bn_bwd_dx"]).items():
-        photo_in_step[k_] = {"us_per_step": sum(v_["all_us"]) / PHOTO_STEPS, "dispatches_per_step": v_["launches"] / PHOTO_STEPS,
+        if PHOTO_STEPS:
+            photo_in_step[k_] = {"us_per_step": sum(v_["all_us"]) / PHOTO_STEPS, "dispatches_per_step": v_["launches"] / PHOTO_STEPS,
                              "max_dispatch_us": max(v_["all_us"])}
     if os.environ.get("MD_BENCH_DUMP_TIMES"):
         for k_ in ("md_costvol_fwd" + sfx, "md_costvol_bwd" + sfx, wild):

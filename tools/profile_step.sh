@@ -10,7 +10,7 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 STEPS=${STEPS:-10}; WARM=${WARM:-3}
 rm -rf /tmp/prof_step
-rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_step -o s -- python $ROOT/bench.py --steps $STEPS --warmup $WARM --no_cpu_baseline --trainer_args="${TRAINER_ARGS:-}" > /tmp/prof_step.log 2>&1
+MD_BENCH_PHOTO_STEPS=0 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_step -o s -- python $ROOT/bench.py --steps $STEPS --warmup $WARM --no_cpu_baseline --trainer_args="${TRAINER_ARGS:-}" > /tmp/prof_step.log 2>&1
 tail -1 /tmp/prof_step.log | cut -c1-300
 python - <<PY
 import csv, json, collections
