@@ -9,14 +9,23 @@ backward.  xGMI is point-to-point (7 links/GPU): ring collectives are per-link b
 gradients go out as a few ~32 MB buckets rather than DDP's default 25 MB x 8 wrappers.
 The hot path itself has no exchange step: every kernel is per-sample.
 """
+import os
+
 import torch
 import torch.distributed as dist
+
+
+def _force():
+    """MD_DP_FORCE_COLLECTIVES=1 (tests on a one-GPU box): a group of one rank still issues every collective, so that the calls, their
+    dtypes and their ordering against the kernels run through RCCL (tests/test_dp_rccl_single_rank_gpu.py)."""
+    return os.environ.get("MD_DP_FORCE_COLLECTIVES", "0") == "1"
 
 
 class GradSync:
     def __init__(self, params, bucket_mb=32.0, process_group=None):
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.active = dist.is_initialized() and (self.world > 1 or _force())
         # reverse order ~ order in which backward produces gradients
         self.params = [p for p in reversed(list(params)) if p.requires_grad]
         self.buckets = []  # (flat tensor, [params])
@@ -51,7 +60,7 @@ class GradSync:
     def _make_hook(self, bi):
         def hook(_p):
             self._pending[bi] -= 1
-            if self._pending[bi] == 0 and self.world > 1:
+            if self._pending[bi] == 0 and self.active:
                 flat = self.buckets[bi][0]
                 self._handles.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
         return hook
@@ -69,7 +78,7 @@ class GradSync:
     def finish(self):
         """Wait for the in-flight buckets, reduce any bucket whose parameters did not all receive a gradient
         this step (unused branches), and turn sums into means (DDP semantics: mean of per-rank gradients)."""
-        if self.world <= 1:
+        if not self.active:
             return
         for bi, n in enumerate(self._pending):
             if n > 0:
@@ -84,7 +93,7 @@ class GradSync:
 
 def broadcast_parameters(modules, src=0, process_group=None):
     """One-time weight/buffer sync from rank 0 (what DDP's constructor does, trainer.py:135)."""
-    if not dist.is_initialized() or dist.get_world_size(process_group) == 1:
+    if not dist.is_initialized() or (dist.get_world_size(process_group) == 1 and not _force()):
         return
     for m in modules:
         for t in list(m.parameters()) + list(m.buffers()):
