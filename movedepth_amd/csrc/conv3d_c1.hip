@@ -687,6 +687,131 @@ __global__ __launch_bounds__(256) void conv3d_c1_fwd16_kernel(const float *__res
     }
 }
 
+// ------------------------------------------------------------------------------------------------ forward, LDS-DMA staging
+// The same tile, thread mapping and arithmetic as conv3d_c1_fwd16_kernel, with the x plane brought in by global_load_lds_dwordx4
+// (memory -> LDS without passing through registers: no staging VGPRs, no ds_write pass -- 612 of the 1380 LDS cycles of a plane).
+// The DMA writes wave-uniform base + lane * 16, so a wave instruction fills 64 consecutive slots of one quad plane (cells in
+// tile row-major order) and the lane's GLOBAL address is that cell's; quad planes are 640 slots apart (10 instructions of 64).
+// Cells outside the image and the 28 surplus slots of a plane read 16 zero bytes (c1_zero16).
+//   NBUF = 1: barrier, issue, wait, barrier, compute -- overlap comes from the other workgroups of the CU (4 fit);
+//   NBUF = 2: plane p + 1 lands in the other buffer while plane p is computed, one barrier per plane (2 workgroups per CU).
+__device__ const float4 c1_zero16 = {0.f, 0.f, 0.f, 0.f};
+namespace fwg {
+constexpr int GP = 640, NI = 4 * GP / 64 / 4;   // quad-plane pitch (slots), instructions per wave and plane (10)
+}
+
+template <int WL, int NBUF>
+__global__ __launch_bounds__(256) void conv3d_c1_fwd16g_kernel(const float *__restrict__ x, const float *__restrict__ wt,
+                                                               float *__restrict__ y, const C1Dims dm) {
+    extern __shared__ float4 gtile[];   // NBUF x 4 x GP
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int col = lane & 31, r0 = wave * 4 + (lane >> 5) * 2;
+    int b, ty0, tx0, d0, d1;
+    {
+        const int item = blockIdx.x;
+        const int sl = item % dm.dslices, t = (item / dm.dslices) % dm.tiles;
+        b = item / (dm.dslices * dm.tiles);
+        tx0 = (t % dm.tiles_x) * fw::FTW;
+        ty0 = (t / dm.tiles_x) * fw::FTH;
+        d0 = sl * dm.planes;
+        d1 = min(d0 + dm.planes, dm.D);
+    }
+    if (d0 >= d1) return;
+    const size_t plane = (size_t)dm.H * dm.W;
+    const float4 *xb = reinterpret_cast<const float4 *>(x) + (size_t)b * dm.D * plane * 4;
+    // instruction j of this wave: global instruction k = wave * NI + j -> quad k / 10, cells 64 * (k % 10) + lane
+    int lofs[fwg::NI];
+#pragma unroll
+    for (int j = 0; j < fwg::NI; ++j) {
+        const int k = wave * fwg::NI + j, qq = k / 10, cell = (k % 10) * 64 + lane;
+        const int yy = ty0 - 1 + cell / fw::FHW, xx = tx0 - 1 + cell % fw::FHW;
+        lofs[j] = (cell < fw::FCELLS && yy >= 0 && yy < dm.H && xx >= 0 && xx < dm.W) ? (yy * dm.W + xx) * 4 + qq : -1;
+    }
+    const int p0 = max(d0 - 1, 0), p1 = min(d1 + 1, dm.D);
+    auto stage = [&](int p, int buf) {
+        const float4 *xp = xb + (size_t)p * plane * 4;
+#pragma unroll
+        for (int j = 0; j < fwg::NI; ++j) {
+            const float4 *src = lofs[j] >= 0 ? xp + lofs[j] : &c1_zero16;
+            float4 *dst = gtile + buf * 4 * fwg::GP + (wave * fwg::NI + j) * 64;   // wave-uniform
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+        }
+    };
+    float acc[2][3][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int kd = 0; kd < 3; ++kd) acc[j][kd][0] = acc[j][kd][1] = 0.f;
+    const int gy0 = ty0 + r0, gx = tx0 + col;
+    if (NBUF == 2) stage(p0, p0 & 1);
+    for (int p = p0; p < p1; ++p) {
+        if (NBUF == 1) {
+            __syncthreads();  // the previous plane's readers are done
+            stage(p, 0);
+        }
+        __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): this wave's pieces have landed
+        __syncthreads();                     // ... and everyone else's
+        if (NBUF == 2 && p + 1 < p1) stage(p + 1, (p + 1) & 1);
+        const float4 *tl = gtile + (NBUF == 2 ? (p & 1) * 4 * fwg::GP : 0) + r0 * fw::FHW + col;
+        auto taps = [&](auto mode) {
+            constexpr int MODE = decltype(mode)::value;
+#pragma unroll 1
+            for (int q = 0; q < 4; ++q) {
+#pragma unroll 1
+                for (int kw = 0; kw < 3; ++kw) {
+                    const float *wq = WL == 0 ? wt + kw * 16 + q * 4 : wt + q * 108 + kw;  // wave-uniform: scalar loads
+                    float4 v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = tl[q * fwg::GP + r * fw::FHW + kw];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const int kh = r - j;
+                            if (kh < 0 || kh > 2) continue;
+#pragma unroll
+                            for (int kd = 0; kd < 3; ++kd) {
+                                if ((MODE == 1 && kd != 0) || (MODE == 2 && kd != 2)) continue;
+                                const int tap9 = kd * 9 + kh * 3;
+                                const float w0 = WL == 0 ? wq[tap9 * 16 + 0] : wq[0 * 27 + tap9];
+                                const float w1 = WL == 0 ? wq[tap9 * 16 + 1] : wq[1 * 27 + tap9];
+                                const float w2 = WL == 0 ? wq[tap9 * 16 + 2] : wq[2 * 27 + tap9];
+                                const float w3 = WL == 0 ? wq[tap9 * 16 + 3] : wq[3 * 27 + tap9];
+                                acc[j][kd][0] = fmaf(v[r].x, w0, acc[j][kd][0]);
+                                acc[j][kd][1] = fmaf(v[r].y, w1, acc[j][kd][1]);
+                                acc[j][kd][0] = fmaf(v[r].z, w2, acc[j][kd][0]);
+                                acc[j][kd][1] = fmaf(v[r].w, w3, acc[j][kd][1]);
+                            }
+                        }
+                }
+            }
+        };
+        if (p < d0) taps(std::integral_constant<int, 1>());
+        else if (p >= d1) taps(std::integral_constant<int, 2>());
+        else taps(std::integral_constant<int, 0>());
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int d = e ? p : p - 1;
+            if (e && p + 1 < dm.D) break;
+            if (d < d0 || d >= d1) continue;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float s = e ? acc[j][1][0] + acc[j][1][1] : acc[j][2][0] + acc[j][2][1];
+                if (gy0 + j < dm.H && gx < dm.W) y[((size_t)b * dm.D + d) * plane + (size_t)(gy0 + j) * dm.W + gx] = s;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                acc[j][2][c] = acc[j][1][c];
+                acc[j][1][c] = acc[j][0][c];
+                acc[j][0][c] = 0.f;
+            }
+    }
+}
+
 int c1_dims(const char *fn, int B, int C, int D, int H, int W, C1Dims &dm) {
     MD_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0, "%s: bad dims B=%d D=%d H=%d W=%d", fn, B, D, H, W);
     MD_REQUIRE(C == 8 || C == 16, "%s: C=%d unsupported (8 or 16 input channels)", fn, C);
@@ -737,7 +862,24 @@ int md_conv3d_c1_fwd(const float *x, const float *wt, long long w_stride_k, long
     const int wl = (w_stride_k == 16 && w_stride_c == 1) ? 0 : (w_stride_k == 1 && w_stride_c == 27) ? 1 : -1;
     if (C == 16 && wl >= 0 && !c1_gen1()) {
         c1_fwd16_dims(dm);
+        // MD_CONV3D_C1_GLDS=1 / 2: LDS-DMA staging, single / double buffered (conv3d_c1_fwd16g_kernel); MD_CONV3D_C1_DS: D slices
+        static const int glds = [] { const char *e = getenv("MD_CONV3D_C1_GLDS"); return e ? atoi(e) : 0; }();
+        static const int dsl = [] { const char *e = getenv("MD_CONV3D_C1_DS"); return e ? atoi(e) : 0; }();
+        if (dsl > 0) { dm.planes = md_cdiv(D, dsl); dm.dslices = md_cdiv(D, dm.planes); dm.per_xcd = 0; }
         const dim3 grid16(dm.per_xcd ? 8 * dm.per_xcd : B * dm.tiles * dm.dslices);
+        if (glds && wl == 0) {
+            const dim3 gridg(B * dm.tiles * dm.dslices);
+            const size_t lds = (size_t)(glds == 2 ? 2 : 1) * 4 * fwg::GP * sizeof(float4);
+            if (glds == 2) {
+                static const hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void *>(conv3d_c1_fwd16g_kernel<0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                MD_REQUIRE(e2 == hipSuccess, "md_conv3d_c1_fwd: cannot raise the dynamic LDS limit");
+                MD_LAUNCH_TIMED("md_conv3d_c1_fwd", (conv3d_c1_fwd16g_kernel<0, 2>), gridg, dim3(256), lds, s, x, wt, y, dm);
+            } else {
+                MD_LAUNCH_TIMED("md_conv3d_c1_fwd", (conv3d_c1_fwd16g_kernel<0, 1>), gridg, dim3(256), lds, s, x, wt, y, dm);
+            }
+            MD_CHECK_LAUNCH("md_conv3d_c1_fwd");
+            return MD_OK;
+        }
         if (wl == 0) MD_LAUNCH_TIMED("md_conv3d_c1_fwd", conv3d_c1_fwd16_kernel<0>, grid16, dim3(256), 0, s, x, wt, y, dm);
         else MD_LAUNCH_TIMED("md_conv3d_c1_fwd", conv3d_c1_fwd16_kernel<1>, grid16, dim3(256), 0, s, x, wt, y, dm);
         MD_CHECK_LAUNCH("md_conv3d_c1_fwd");
