@@ -571,7 +571,8 @@ static_assert(PITCH % 16 == 4, "quad planes must sit 4 slots apart");
 }  // namespace fw
 
 // WL = 0: weight in channels-last order (tap stride 16, channel stride 1); WL = 1: planar (tap stride 1, channel stride 27).
-template <int WL>
+// PF2: x planes fetched TWO steps ahead (two register sets that swap roles; 3 waves per SIMD) -- MD_CONV3D_C1_PF2=1, an A/B variant
+template <int WL, bool PF2 = false>
 __global__ __launch_bounds__(256) void conv3d_c1_fwd16_kernel(const float *__restrict__ x, const float *__restrict__ wt,
                                                               float *__restrict__ y, const C1Dims dm) {
     __shared__ float4 tile[fw::FNLD * 256];
@@ -608,24 +609,25 @@ __global__ __launch_bounds__(256) void conv3d_c1_fwd16_kernel(const float *__res
         sofs[i] = idx < fw::FCELLS * 4 ? qq * fw::PITCH + cell : idx;
     }
     const int p0 = max(d0 - 1, 0), p1 = min(d1 + 1, dm.D);
-    float4 pre[fw::FNLD];
-    auto fetch = [&](int p) {
+    float4 preA[fw::FNLD], preB[fw::FNLD];
+    auto fetch = [&](int p, float4 (&pre)[fw::FNLD]) {
 #pragma unroll
         for (int i = 0; i < fw::FNLD; ++i) pre[i] = xb[(size_t)p * plane * 4 + max(lofs[i], 0)];
     };
-    fetch(p0);
+    fetch(p0, preA);
+    if (PF2 && p0 + 1 < p1) fetch(p0 + 1, preB);
     float acc[2][3][2];  // [voxel][kd][even / odd channel chain]
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int kd = 0; kd < 3; ++kd) acc[j][kd][0] = acc[j][kd][1] = 0.f;
     const int gy0 = ty0 + r0, gx = tx0 + col;
-    for (int p = p0; p < p1; ++p) {
+    auto step = [&](int p, float4 (&pre)[fw::FNLD]) {
         __syncthreads();  // the previous plane's readers are done
 #pragma unroll
         for (int i = 0; i < fw::FNLD; ++i) tile[sofs[i]] = lofs[i] >= 0 ? pre[i] : make_float4(0.f, 0.f, 0.f, 0.f);
         __syncthreads();
-        if (p + 1 < p1) fetch(p + 1);
+        if (p + (PF2 ? 2 : 1) < p1) fetch(p + (PF2 ? 2 : 1), pre);
         const float4 *tl = tile + r0 * fw::FHW + col;
         // MODE 0: every kd; 1: the halo plane below the slice (only tap kd = 0, output d0); 2: the one above (only kd = 2)
         auto taps = [&](auto mode) {
@@ -684,6 +686,14 @@ __global__ __launch_bounds__(256) void conv3d_c1_fwd16_kernel(const float *__res
                 acc[j][1][c] = acc[j][0][c];
                 acc[j][0][c] = 0.f;
             }
+    };
+    if (PF2) {
+        for (int p = p0; p < p1; p += 2) {
+            step(p, preA);
+            if (p + 1 < p1) step(p + 1, preB);
+        }
+    } else {
+        for (int p = p0; p < p1; ++p) step(p, preA);
     }
 }
 
@@ -880,7 +890,9 @@ int md_conv3d_c1_fwd(const float *x, const float *wt, long long w_stride_k, long
             MD_CHECK_LAUNCH("md_conv3d_c1_fwd");
             return MD_OK;
         }
-        if (wl == 0) MD_LAUNCH_TIMED("md_conv3d_c1_fwd", conv3d_c1_fwd16_kernel<0>, grid16, dim3(256), 0, s, x, wt, y, dm);
+        static const bool pf2 = [] { const char *e = getenv("MD_CONV3D_C1_PF2"); return e && *e == '1'; }();
+        if (wl == 0 && pf2) MD_LAUNCH_TIMED("md_conv3d_c1_fwd", (conv3d_c1_fwd16_kernel<0, true>), grid16, dim3(256), 0, s, x, wt, y, dm);
+        else if (wl == 0) MD_LAUNCH_TIMED("md_conv3d_c1_fwd", conv3d_c1_fwd16_kernel<0>, grid16, dim3(256), 0, s, x, wt, y, dm);
         else MD_LAUNCH_TIMED("md_conv3d_c1_fwd", conv3d_c1_fwd16_kernel<1>, grid16, dim3(256), 0, s, x, wt, y, dm);
         MD_CHECK_LAUNCH("md_conv3d_c1_fwd");
         return MD_OK;
