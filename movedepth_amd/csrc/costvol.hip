@@ -847,8 +847,9 @@ int launch_cl(const CvPtrs &q, CvDims dm, hipStream_t stream) {
 #define MD_CL_FWD_NW 8
 #endif
     constexpr int NW = BWD ? 4 : MD_CL_FWD_NW;
-    dm.tiles_x = md_cdiv(dm.w, TW);
-    dm.tiles = dm.tiles_x * md_cdiv(dm.h, NW);
+    constexpr int WX = BWD ? 1 : MD_CL_FWD_WX;   // forward tile (TW * WX) x (NW / WX), costvol_cl.inc
+    dm.tiles_x = md_cdiv(dm.w, TW * WX);
+    dm.tiles = dm.tiles_x * md_cdiv(dm.h, NW / WX);
     dm.splits = 1;
     dm.items = dm.B * dm.tiles;
     dm.dbg = 0;
