@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-4 profile bundle (run on the GPU box through gpurun): tools/r04_profiles.sh <stage ...>   (stages: bench step pmc wild cfg syncbn n2)
+# Round-4 profile bundle (run on the GPU box through gpurun): tools/r04_profiles.sh <stage ...>   (stages: bench step pmc wild cfg syncbn syncbn_trace n2)
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 O=$GRAFT_REPO_ROOT/gpurun_out/r04_profiles; mkdir -p $O
@@ -36,6 +36,9 @@ syncbn)
     python tools/micro/bn_host_overhead.py 2>&1 | grep -v amdgpu.ids; } > $O/r04_syncbn.txt 2>&1
   TRAINER_ARGS="--force_sync_bn 1" timeout 1500 bash tools/profile_step.sh $O/r04_bench_kernel_stats_syncbn.csv > $O/r04_bench_kernel_stats_syncbn.log 2>&1
   head -14 $O/r04_syncbn.txt ;;
+syncbn_trace)
+  TRAINER_ARGS="--force_sync_bn 1" timeout 1500 bash tools/profile_step.sh $O/r04_bench_kernel_stats_syncbn.csv > $O/r04_bench_kernel_stats_syncbn.log 2>&1
+  grep "^# " $O/r04_bench_kernel_stats_syncbn.csv | head -16 ;;
 n2)
   MD_SHARE_GPU=1 timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 5 --warmup 3 > $O/r04_bench_n2_shared_gpu_gloo.json 2> $O/n2.err; tail -c 600 $O/r04_bench_n2_shared_gpu_gloo.json ;;
 esac; done
