@@ -25,7 +25,6 @@ class GradSync:
     def __init__(self, params, bucket_mb=32.0, process_group=None):
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
-        self.active = dist.is_initialized() and (self.world > 1 or _force())
         # reverse order ~ order in which backward produces gradients
         self.params = [p for p in reversed(list(params)) if p.requires_grad]
         self.buckets = []  # (flat tensor, [params])
@@ -46,6 +45,11 @@ class GradSync:
             for p in ps:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(bi)))
         self.reset()
+
+    @property
+    def active(self):
+        """collectives are issued: more than one rank (tests switch the reducer off by setting .world = 1), or forced"""
+        return dist.is_initialized() and (self.world > 1 or _force())
 
     def _close(self, ps):
         n = sum(p.numel() for p in ps)
