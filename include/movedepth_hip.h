@@ -302,16 +302,18 @@ int md_conv3d_c16_bwd_weight(const float *x, int x_planar, const float *gy, floa
  * ws: md_bn_ws_bytes() bytes, ZEROED ONCE by the caller and then reused (the reduction kernels leave it zeroed); one
  * workspace per stream. */
 size_t md_bn_ws_bytes(void);
-int md_bn_stats(const float *x, long long nrows, int C, double *sums, void *ws, md_stream_t stream);
-int md_bn_apply(const float *x, const double *sums, long long n_total, float eps, float momentum, const float *gamma,
-                const float *beta, int relu, float *running_mean, float *running_var, float *stat, float *y, long long nrows,
+/* dtype = element type of the activations and their gradients (x, y, dy, dx): 0 float, 1 bf16, 2 fp16 -- what torch.autocast hands
+ * a BatchNorm layer and expects back (ABI 14).  Sums, statistics, gamma / beta and their gradients are float / double in every case. */
+int md_bn_stats(const void *x, int dtype, long long nrows, int C, double *sums, void *ws, md_stream_t stream);
+int md_bn_apply(const void *x, int dtype, const double *sums, long long n_total, float eps, float momentum, const float *gamma,
+                const float *beta, int relu, float *running_mean, float *running_var, float *stat, void *y, long long nrows,
                 int C, md_stream_t stream);
-int md_bn_eval(const float *x, const float *running_mean, const float *running_var, float eps, const float *gamma,
-               const float *beta, int relu, float *y, long long nrows, int C, md_stream_t stream);
-int md_bn_bwd_reduce(const float *dy, const float *x, const float *stat, const float *gamma, const float *beta, int relu,
+int md_bn_eval(const void *x, int dtype, const float *running_mean, const float *running_var, float eps, const float *gamma,
+               const float *beta, int relu, void *y, long long nrows, int C, md_stream_t stream);
+int md_bn_bwd_reduce(const void *dy, const void *x, int dtype, const float *stat, const float *gamma, const float *beta, int relu,
                      long long nrows, int C, float *sums, void *ws, md_stream_t stream);
-int md_bn_bwd_dx(const float *dy, const float *x, const float *stat, const float *gamma, const float *beta, int relu,
-                 const float *sums, long long n_total, long long nrows, int C, float *dx, md_stream_t stream);
+int md_bn_bwd_dx(const void *dy, const void *x, int dtype, const float *stat, const float *gamma, const float *beta, int relu,
+                 const float *sums, long long n_total, long long nrows, int C, void *dx, md_stream_t stream);
 
 /* ---- training-mode BatchNorm + ReLU (+ residual) of the regulariser's two full-resolution layers -------------
  * conv0's BatchNorm3d + ReLU (networks/resnet_encoder.py:231 through ConvBnReLU3D) and conv11's BatchNorm3d + ReLU

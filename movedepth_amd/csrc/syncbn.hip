@@ -57,10 +57,43 @@ __host__ inline bool bn_geo(long long nrows, int C, BnGeo &g) {
 }
 
 __device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
-__device__ __forceinline__ float4 ld_stream(const float4 *p) {   // read-once streams: non-temporal (DESIGN 4.1 "cache policy")
+// Element types of the activations and their gradients (x, y, dy, dx): float, or the 2-byte types of a mixed-precision step
+// (torch.autocast hands BatchNorm its input in bf16 / fp16 and expects the output in the same type; sums, statistics, gamma,
+// beta and their gradients stay fp32 / double as in the library's kernels).  A piece = 4 channels = 16 or 8 bytes.
+struct bf16_t { unsigned short v; };
+struct f16_t { _Float16 v; };
+__device__ __forceinline__ float4 ld_stream(const float *p, long long i) {   // read-once streams: non-temporal (DESIGN 4.1 "cache policy")
     typedef float nt4_t __attribute__((ext_vector_type(4)));
-    const nt4_t v = __builtin_nontemporal_load(reinterpret_cast<const nt4_t *>(p));
+    const nt4_t v = __builtin_nontemporal_load(reinterpret_cast<const nt4_t *>(p) + i);
     return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ float4 ld_stream(const bf16_t *p, long long i) {
+    typedef unsigned nt2_t __attribute__((ext_vector_type(2)));
+    const nt2_t v = __builtin_nontemporal_load(reinterpret_cast<const nt2_t *>(p) + i);
+    return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u));
+}
+__device__ __forceinline__ float4 ld_stream(const f16_t *p, long long i) {
+    // (halves taken out of the two dwords one by one: with the dwords bit-cast to 2-vectors of _Float16 the compiler loaded only
+    // the first dword of the piece -- channels 2 and 3 of every quad came out wrong)
+    typedef unsigned nt2_t __attribute__((ext_vector_type(2)));
+    const nt2_t v = __builtin_nontemporal_load(reinterpret_cast<const nt2_t *>(p) + i);
+    const unsigned lo = v.x, hi = v.y;
+    return make_float4((float)__builtin_bit_cast(_Float16, (unsigned short)(lo & 0xffffu)), (float)__builtin_bit_cast(_Float16, (unsigned short)(lo >> 16)),
+                       (float)__builtin_bit_cast(_Float16, (unsigned short)(hi & 0xffffu)), (float)__builtin_bit_cast(_Float16, (unsigned short)(hi >> 16)));
+}
+__device__ __forceinline__ void st_piece(float *p, long long i, float4 o) { reinterpret_cast<float4 *>(p)[i] = o; }
+__device__ __forceinline__ unsigned bf16_rn(float f) {   // round to nearest even (NaN kept quiet), as torch's conversion
+    const unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ void st_piece(bf16_t *p, long long i, float4 o) {
+    reinterpret_cast<uint2 *>(p)[i] = make_uint2(bf16_rn(o.x) | (bf16_rn(o.y) << 16), bf16_rn(o.z) | (bf16_rn(o.w) << 16));
+}
+__device__ __forceinline__ void st_piece(f16_t *p, long long i, float4 o) {
+    const unsigned a = (unsigned)__builtin_bit_cast(unsigned short, (_Float16)o.x) | ((unsigned)__builtin_bit_cast(unsigned short, (_Float16)o.y) << 16);
+    const unsigned b = (unsigned)__builtin_bit_cast(unsigned short, (_Float16)o.z) | ((unsigned)__builtin_bit_cast(unsigned short, (_Float16)o.w) << 16);
+    reinterpret_cast<uint2 *>(p)[i] = make_uint2(a, b);
 }
 
 // Sum of the per-thread values a, b over the threads of the block that own the same channel quad -> partial[blk][0][C] (a) and
@@ -148,7 +181,8 @@ __device__ __forceinline__ void bn_block_finish(float4 a, float4 b, int QN, floa
     if (tid == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch on this workspace
 }
 
-__global__ void bn_stats_kernel(const float4 *__restrict__ x, BnGeo g, float *__restrict__ partial, unsigned *__restrict__ counter,
+template <typename IO>
+__global__ void bn_stats_kernel(const IO *__restrict__ x, BnGeo g, float *__restrict__ partial, unsigned *__restrict__ counter,
                                 double *__restrict__ sums) {
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f), ss = s;
     const long long stride = (long long)gridDim.x * blockDim.x;   // a multiple of QN: the thread stays on one quad
@@ -156,7 +190,7 @@ __global__ void bn_stats_kernel(const float4 *__restrict__ x, BnGeo g, float *__
     for (; i + 3 * stride < g.npieces; i += 4 * stride) {
         float4 v[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = ld_stream(x + i + u * stride);
+        for (int u = 0; u < 4; ++u) v[u] = ld_stream(x, i + u * stride);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             s = f4add(s, v[u]);
@@ -165,7 +199,7 @@ __global__ void bn_stats_kernel(const float4 *__restrict__ x, BnGeo g, float *__
         }
     }
     for (; i < g.npieces; i += stride) {
-        const float4 v = ld_stream(x + i);
+        const float4 v = ld_stream(x, i);
         s = f4add(s, v);
         ss.x = fmaf(v.x, v.x, ss.x); ss.y = fmaf(v.y, v.y, ss.y); ss.z = fmaf(v.z, v.z, ss.z); ss.w = fmaf(v.w, v.w, ss.w);
     }
@@ -211,11 +245,11 @@ __device__ __forceinline__ BnQuad bn_quad_from_stat(const float *__restrict__ st
     return r;
 }
 
-template <bool RELU>
-__global__ void bn_apply_kernel(const float4 *__restrict__ x, BnGeo g, const double *__restrict__ sums, double inv_n, double unbias, float eps,
+template <bool RELU, typename IO>
+__global__ void bn_apply_kernel(const IO *__restrict__ x, BnGeo g, const double *__restrict__ sums, double inv_n, double unbias, float eps,
                                 float momentum, const float *__restrict__ gamma, const float *__restrict__ beta,
                                 float *__restrict__ running_mean, float *__restrict__ running_var, float *__restrict__ stat,
-                                float4 *__restrict__ y) {
+                                IO *__restrict__ y) {
     // mean / invstd in double (divisions, a square root: ~100 instructions per channel): once per block and channel quad, handed
     // to the block's threads through LDS -- per thread, as first written, that arithmetic was a third of the kernel on large grids
     extern __shared__ float4 shc[];   // [2][QN]: scale, shift
@@ -244,17 +278,17 @@ __global__ void bn_apply_kernel(const float4 *__restrict__ x, BnGeo g, const dou
     const float4 sc4 = shc[q], sf4 = shc[g.QN + q];
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < g.npieces; i += stride) {
-        const float4 v = ld_stream(x + i);
+        const float4 v = ld_stream(x, i);
         float4 o = make_float4(fmaf(v.x, sc4.x, sf4.x), fmaf(v.y, sc4.y, sf4.y), fmaf(v.z, sc4.z, sf4.z), fmaf(v.w, sc4.w, sf4.w));
         if (RELU) o = make_float4(fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f));
-        y[i] = o;
+        st_piece(y, i, o);
     }
 }
 
 // evaluation mode: y = (x - running_mean) / sqrt(running_var + eps) * gamma + beta [relu]
-template <bool RELU>
-__global__ void bn_eval_kernel(const float4 *__restrict__ x, BnGeo g, const float *__restrict__ rm, const float *__restrict__ rv,
-                               float eps, const float *__restrict__ gamma, const float *__restrict__ beta, float4 *__restrict__ y) {
+template <bool RELU, typename IO>
+__global__ void bn_eval_kernel(const IO *__restrict__ x, BnGeo g, const float *__restrict__ rm, const float *__restrict__ rv,
+                               float eps, const float *__restrict__ gamma, const float *__restrict__ beta, IO *__restrict__ y) {
     const int q = (int)(((long long)blockIdx.x * blockDim.x + threadIdx.x) % g.QN);
     float sc[4], sf[4];
 #pragma unroll
@@ -266,15 +300,15 @@ __global__ void bn_eval_kernel(const float4 *__restrict__ x, BnGeo g, const floa
     }
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < g.npieces; i += stride) {
-        const float4 v = x[i];
+        const float4 v = ld_stream(x, i);
         float4 o = make_float4(fmaf(v.x, sc[0], sf[0]), fmaf(v.y, sc[1], sf[1]), fmaf(v.z, sc[2], sf[2]), fmaf(v.w, sc[3], sf[3]));
         if (RELU) o = make_float4(fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f));
-        y[i] = o;
+        st_piece(y, i, o);
     }
 }
 
-template <bool RELU>
-__global__ void bn_bwd_reduce_kernel(const float4 *__restrict__ dy, const float4 *__restrict__ x, BnGeo g, const float *__restrict__ stat,
+template <bool RELU, typename IO>
+__global__ void bn_bwd_reduce_kernel(const IO *__restrict__ dy, const IO *__restrict__ x, BnGeo g, const float *__restrict__ stat,
                                      const float *__restrict__ gamma, const float *__restrict__ beta, float *__restrict__ partial,
                                      unsigned *__restrict__ counter, float *__restrict__ sums) {
     const int q = (int)(((long long)blockIdx.x * blockDim.x + threadIdx.x) % g.QN);
@@ -295,18 +329,18 @@ __global__ void bn_bwd_reduce_kernel(const float4 *__restrict__ dy, const float4
         sx = f4add(sx, make_float4(b[0], b[1], b[2], b[3]));
     };
     for (; i + stride < g.npieces; i += 2 * stride) {
-        const float4 v0 = ld_stream(x + i), g0 = ld_stream(dy + i), v1 = ld_stream(x + i + stride), g1 = ld_stream(dy + i + stride);
+        const float4 v0 = ld_stream(x, i), g0 = ld_stream(dy, i), v1 = ld_stream(x, i + stride), g1 = ld_stream(dy, i + stride);
         acc(v0, g0);
         acc(v1, g1);
     }
-    for (; i < g.npieces; i += stride) acc(ld_stream(x + i), ld_stream(dy + i));
+    for (; i < g.npieces; i += stride) acc(ld_stream(x, i), ld_stream(dy, i));
     bn_block_finish<float>(s, sx, g.QN, partial, counter, sums);
 }
 
-template <bool RELU>
-__global__ void bn_bwd_dx_kernel(const float4 *__restrict__ dy, const float4 *__restrict__ x, BnGeo g, const float *__restrict__ stat,
+template <bool RELU, typename IO>
+__global__ void bn_bwd_dx_kernel(const IO *__restrict__ dy, const IO *__restrict__ x, BnGeo g, const float *__restrict__ stat,
                                  const float *__restrict__ gamma, const float *__restrict__ beta, const float *__restrict__ sums,
-                                 float inv_n, float4 *__restrict__ dx) {
+                                 float inv_n, IO *__restrict__ dx) {
     const int q = (int)(((long long)blockIdx.x * blockDim.x + threadIdx.x) % g.QN);
     const BnQuad c = bn_quad_from_stat(stat, g.C, q, gamma, beta);
     float m1[4], m2[4], gi[4];
@@ -318,7 +352,7 @@ __global__ void bn_bwd_dx_kernel(const float4 *__restrict__ dy, const float4 *__
     }
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < g.npieces; i += stride) {
-        const float4 v = ld_stream(x + i), gq = ld_stream(dy + i);
+        const float4 v = ld_stream(x, i), gq = ld_stream(dy, i);
         const float xv[4] = {v.x, v.y, v.z, v.w}, gv[4] = {gq.x, gq.y, gq.z, gq.w};
         float o[4];
 #pragma unroll
@@ -327,7 +361,7 @@ __global__ void bn_bwd_dx_kernel(const float4 *__restrict__ dy, const float4 *__
             const float dz = (!RELU || fmaf(xv[k], c.sc[k], c.sf[k]) > 0.f) ? gv[k] : 0.f;
             o[k] = gi[k] * (dz - m1[k] - xh * m2[k]);
         }
-        dx[i] = make_float4(o[0], o[1], o[2], o[3]);
+        st_piece(dx, i, make_float4(o[0], o[1], o[2], o[3]));
     }
 }
 
@@ -350,21 +384,30 @@ extern "C" {
 
 size_t md_bn_ws_bytes(void) { return 256 + sizeof(float) * (size_t)(BN_MAX_PARTIAL_FLOATS + 2 * 4096 * 8); }
 
-int md_bn_stats(const float *x, long long nrows, int C, double *sums, void *ws, md_stream_t stream) {
+// dtype of x / y / dy / dx: 0 float, 1 bf16, 2 fp16
+#define BN_BY_DTYPE(fn, dtype, CALL)                                                                  \
+    switch (dtype) {                                                                                    \
+        case 0: { using IO = float; CALL; } break;                                                      \
+        case 1: { using IO = bf16_t; CALL; } break;                                                     \
+        case 2: { using IO = f16_t; CALL; } break;                                                      \
+        default: MD_REQUIRE(false, "%s: dtype %d (0 float, 1 bf16, 2 fp16)", fn, dtype);                \
+    }
+
+int md_bn_stats(const void *x, int dtype, long long nrows, int C, double *sums, void *ws, md_stream_t stream) {
     MD_REQUIRE(x && sums && ws, "md_bn_stats: null tensor argument");
-    MD_REQUIRE(((uintptr_t)x % 16) == 0, "md_bn_stats: x must be 16-byte aligned");
+    MD_REQUIRE(((uintptr_t)x % (dtype ? 8 : 16)) == 0, "md_bn_stats: x must be aligned to a 4-channel piece");
     BnGeo g;
     if (int rc = bn_args("md_bn_stats", nrows, C, g)) return rc;
     unsigned *counter = (unsigned *)ws;
     float *partial = (float *)((char *)ws + 256);
-    MD_LAUNCH_TIMED("md_bn_stats", bn_stats_kernel, dim3(g.nblk), dim3(g.NTR), 2 * g.NTR * sizeof(float4), (hipStream_t)stream,
-                    (const float4 *)x, g, partial, counter, sums);
+    BN_BY_DTYPE("md_bn_stats", dtype, MD_LAUNCH_TIMED("md_bn_stats", bn_stats_kernel<IO>, dim3(g.nblk), dim3(g.NTR), 2 * g.NTR * sizeof(float4),
+                                                      (hipStream_t)stream, (const IO *)x, g, partial, counter, sums))
     MD_CHECK_LAUNCH("md_bn_stats");
     return MD_OK;
 }
 
-int md_bn_apply(const float *x, const double *sums, long long n_total, float eps, float momentum, const float *gamma,
-                const float *beta, int relu, float *running_mean, float *running_var, float *stat, float *y, long long nrows, int C,
+int md_bn_apply(const void *x, int dtype, const double *sums, long long n_total, float eps, float momentum, const float *gamma,
+                const float *beta, int relu, float *running_mean, float *running_var, float *stat, void *y, long long nrows, int C,
                 md_stream_t stream) {
     MD_REQUIRE(x && sums && gamma && beta && stat && y, "md_bn_apply: null tensor argument");
     MD_REQUIRE(n_total >= nrows, "md_bn_apply: n_total %lld < rows %lld", n_total, nrows);
@@ -373,27 +416,29 @@ int md_bn_apply(const float *x, const double *sums, long long n_total, float eps
     const dim3 grid(bn_ew_grid(g)), block(g.NT);
     const size_t lds = 2 * (size_t)g.QN * sizeof(float4);
     const double inv_n = 1.0 / (double)n_total, unbias = n_total > 1 ? (double)n_total / (double)(n_total - 1) : 1.0;
-    if (relu) MD_LAUNCH_TIMED("md_bn_apply", bn_apply_kernel<true>, grid, block, lds, (hipStream_t)stream, (const float4 *)x, g, sums, inv_n, unbias,
-                              eps, momentum, gamma, beta, running_mean, running_var, stat, (float4 *)y);
-    else MD_LAUNCH_TIMED("md_bn_apply", bn_apply_kernel<false>, grid, block, lds, (hipStream_t)stream, (const float4 *)x, g, sums, inv_n, unbias,
-                         eps, momentum, gamma, beta, running_mean, running_var, stat, (float4 *)y);
+    if (relu) { BN_BY_DTYPE("md_bn_apply", dtype, MD_LAUNCH_TIMED("md_bn_apply", (bn_apply_kernel<true, IO>), grid, block, lds, (hipStream_t)stream, (const IO *)x, g, sums,
+                                                                  inv_n, unbias, eps, momentum, gamma, beta, running_mean, running_var, stat, (IO *)y)) }
+    else { BN_BY_DTYPE("md_bn_apply", dtype, MD_LAUNCH_TIMED("md_bn_apply", (bn_apply_kernel<false, IO>), grid, block, lds, (hipStream_t)stream, (const IO *)x, g, sums,
+                                                             inv_n, unbias, eps, momentum, gamma, beta, running_mean, running_var, stat, (IO *)y)) }
     MD_CHECK_LAUNCH("md_bn_apply");
     return MD_OK;
 }
 
-int md_bn_eval(const float *x, const float *running_mean, const float *running_var, float eps, const float *gamma, const float *beta,
-               int relu, float *y, long long nrows, int C, md_stream_t stream) {
+int md_bn_eval(const void *x, int dtype, const float *running_mean, const float *running_var, float eps, const float *gamma, const float *beta,
+               int relu, void *y, long long nrows, int C, md_stream_t stream) {
     MD_REQUIRE(x && running_mean && running_var && gamma && beta && y, "md_bn_eval: null tensor argument");
     BnGeo g;
     if (int rc = bn_args("md_bn_eval", nrows, C, g)) return rc;
     const dim3 grid(bn_ew_grid(g)), block(g.NT);
-    if (relu) hipLaunchKernelGGL(bn_eval_kernel<true>, grid, block, 0, (hipStream_t)stream, (const float4 *)x, g, running_mean, running_var, eps, gamma, beta, (float4 *)y);
-    else hipLaunchKernelGGL(bn_eval_kernel<false>, grid, block, 0, (hipStream_t)stream, (const float4 *)x, g, running_mean, running_var, eps, gamma, beta, (float4 *)y);
+    if (relu) { BN_BY_DTYPE("md_bn_eval", dtype, hipLaunchKernelGGL((bn_eval_kernel<true, IO>), grid, block, 0, (hipStream_t)stream, (const IO *)x, g, running_mean, running_var,
+                                                                    eps, gamma, beta, (IO *)y)) }
+    else { BN_BY_DTYPE("md_bn_eval", dtype, hipLaunchKernelGGL((bn_eval_kernel<false, IO>), grid, block, 0, (hipStream_t)stream, (const IO *)x, g, running_mean, running_var,
+                                                               eps, gamma, beta, (IO *)y)) }
     MD_CHECK_LAUNCH("md_bn_eval");
     return MD_OK;
 }
 
-int md_bn_bwd_reduce(const float *dy, const float *x, const float *stat, const float *gamma, const float *beta, int relu,
+int md_bn_bwd_reduce(const void *dy, const void *x, int dtype, const float *stat, const float *gamma, const float *beta, int relu,
                      long long nrows, int C, float *sums, void *ws, md_stream_t stream) {
     MD_REQUIRE(dy && x && stat && gamma && beta && sums && ws, "md_bn_bwd_reduce: null tensor argument");
     BnGeo g;
@@ -401,25 +446,25 @@ int md_bn_bwd_reduce(const float *dy, const float *x, const float *stat, const f
     unsigned *counter = (unsigned *)ws;
     float *partial = (float *)((char *)ws + 256);
     const size_t lds = 2 * g.NTR * sizeof(float4);
-    if (relu) MD_LAUNCH_TIMED("md_bn_bwd_reduce", bn_bwd_reduce_kernel<true>, dim3(g.nblk), dim3(g.NTR), lds, (hipStream_t)stream, (const float4 *)dy,
-                              (const float4 *)x, g, stat, gamma, beta, partial, counter, sums);
-    else MD_LAUNCH_TIMED("md_bn_bwd_reduce", bn_bwd_reduce_kernel<false>, dim3(g.nblk), dim3(g.NTR), lds, (hipStream_t)stream, (const float4 *)dy,
-                         (const float4 *)x, g, stat, gamma, beta, partial, counter, sums);
+    if (relu) { BN_BY_DTYPE("md_bn_bwd_reduce", dtype, MD_LAUNCH_TIMED("md_bn_bwd_reduce", (bn_bwd_reduce_kernel<true, IO>), dim3(g.nblk), dim3(g.NTR), lds, (hipStream_t)stream,
+                                                                       (const IO *)dy, (const IO *)x, g, stat, gamma, beta, partial, counter, sums)) }
+    else { BN_BY_DTYPE("md_bn_bwd_reduce", dtype, MD_LAUNCH_TIMED("md_bn_bwd_reduce", (bn_bwd_reduce_kernel<false, IO>), dim3(g.nblk), dim3(g.NTR), lds, (hipStream_t)stream,
+                                                                  (const IO *)dy, (const IO *)x, g, stat, gamma, beta, partial, counter, sums)) }
     MD_CHECK_LAUNCH("md_bn_bwd_reduce");
     return MD_OK;
 }
 
-int md_bn_bwd_dx(const float *dy, const float *x, const float *stat, const float *gamma, const float *beta, int relu,
-                 const float *sums, long long n_total, long long nrows, int C, float *dx, md_stream_t stream) {
+int md_bn_bwd_dx(const void *dy, const void *x, int dtype, const float *stat, const float *gamma, const float *beta, int relu,
+                 const float *sums, long long n_total, long long nrows, int C, void *dx, md_stream_t stream) {
     MD_REQUIRE(dy && x && stat && gamma && beta && sums && dx, "md_bn_bwd_dx: null tensor argument");
     MD_REQUIRE(n_total >= nrows, "md_bn_bwd_dx: n_total %lld < rows %lld", n_total, nrows);
     BnGeo g;
     if (int rc = bn_args("md_bn_bwd_dx", nrows, C, g)) return rc;
     const dim3 grid(bn_ew_grid(g)), block(g.NT);
-    if (relu) MD_LAUNCH_TIMED("md_bn_bwd_dx", bn_bwd_dx_kernel<true>, grid, block, 0, (hipStream_t)stream, (const float4 *)dy, (const float4 *)x, g, stat,
-                              gamma, beta, sums, 1.f / (float)n_total, (float4 *)dx);
-    else MD_LAUNCH_TIMED("md_bn_bwd_dx", bn_bwd_dx_kernel<false>, grid, block, 0, (hipStream_t)stream, (const float4 *)dy, (const float4 *)x, g, stat,
-                         gamma, beta, sums, 1.f / (float)n_total, (float4 *)dx);
+    if (relu) { BN_BY_DTYPE("md_bn_bwd_dx", dtype, MD_LAUNCH_TIMED("md_bn_bwd_dx", (bn_bwd_dx_kernel<true, IO>), grid, block, 0, (hipStream_t)stream, (const IO *)dy, (const IO *)x, g,
+                                                                   stat, gamma, beta, sums, 1.f / (float)n_total, (IO *)dx)) }
+    else { BN_BY_DTYPE("md_bn_bwd_dx", dtype, MD_LAUNCH_TIMED("md_bn_bwd_dx", (bn_bwd_dx_kernel<false, IO>), grid, block, 0, (hipStream_t)stream, (const IO *)dy, (const IO *)x, g,
+                                                              stat, gamma, beta, sums, 1.f / (float)n_total, (IO *)dx)) }
     MD_CHECK_LAUNCH("md_bn_bwd_dx");
     return MD_OK;
 }

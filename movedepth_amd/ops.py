@@ -1009,10 +1009,15 @@ def _bn_ws(device, stream):
     return ws[1]
 
 
-def _rows_channels_last(x):
-    """x (N,C,*spatial) -> (float32 tensor stored channels-last, rows, C); a copy only if it is not stored that way already"""
-    if x.dtype is not torch.float32:
-        x = x.float()
+_BN_DTYPE = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}   # `dtype` of md_bn_* (include/movedepth_hip.h)
+
+
+def _rows_channels_last(x, dtype=None):
+    """x (N,C,*spatial) -> (tensor stored channels-last, rows, C); float32, bf16 and fp16 (what torch.autocast hands a BatchNorm) stay
+    as they are -- or become `dtype` --, anything else becomes float32; a copy only if it is not stored that way already"""
+    want = dtype if dtype is not None else (x.dtype if x.dtype in _BN_DTYPE else torch.float32)
+    if x.dtype is not want:
+        x = x.to(want)
     nd = x.dim()
     if nd == 2:
         if not x.is_contiguous():
@@ -1045,7 +1050,8 @@ class _SyncBatchNorm(torch.autograd.Function):
         buf = torch.empty(3 * C, device=dev, dtype=torch.float64)
         sums = buf[:2 * C]
         stat = buf[2 * C:].view(torch.float32)
-        rc = f_stats(x.data_ptr(), rows, C, sums.data_ptr(), _bn_ws(dev, stream), stream)
+        dt = _BN_DTYPE[x.dtype]
+        rc = f_stats(x.data_ptr(), dt, rows, C, sums.data_ptr(), _bn_ws(dev, stream), stream)
         if rc:
             _lib.check(rc, "md_bn_stats")
         n_total = rows
@@ -1058,7 +1064,7 @@ class _SyncBatchNorm(torch.autograd.Function):
         w, b = _f32c(weight), _f32c(bias)
         rm = running_mean.data_ptr() if (running_mean is not None and running_mean.dtype is torch.float32) else None
         rv = running_var.data_ptr() if (running_var is not None and running_var.dtype is torch.float32) else None
-        rc = f_apply(x.data_ptr(), sums.data_ptr(), n_total, eps, momentum, w.data_ptr(), b.data_ptr(), relu, rm, rv, stat.data_ptr(),
+        rc = f_apply(x.data_ptr(), dt, sums.data_ptr(), n_total, eps, momentum, w.data_ptr(), b.data_ptr(), relu, rm, rv, stat.data_ptr(),
                      y.data_ptr(), rows, C, stream)
         if rc:
             _lib.check(rc, "md_bn_apply")
@@ -1069,12 +1075,13 @@ class _SyncBatchNorm(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, stat, w, b = ctx.saved_tensors
-        dy, rows, C = _rows_channels_last(dy)
+        dy, rows, C = _rows_channels_last(dy, x.dtype)
+        dt = _BN_DTYPE[x.dtype]
         dev = x.device
         stream = torch._C._cuda_getCurrentRawStream(dev.index)
         _, _, f_reduce, f_dx = _bn_fns()
         sums = torch.empty(2 * C, device=dev, dtype=torch.float32)
-        rc = f_reduce(dy.data_ptr(), x.data_ptr(), stat.data_ptr(), w.data_ptr(), b.data_ptr(), ctx.relu, rows, C, sums.data_ptr(),
+        rc = f_reduce(dy.data_ptr(), x.data_ptr(), dt, stat.data_ptr(), w.data_ptr(), b.data_ptr(), ctx.relu, rows, C, sums.data_ptr(),
                       _bn_ws(dev, stream), stream)
         if rc:
             _lib.check(rc, "md_bn_bwd_reduce")
@@ -1086,7 +1093,7 @@ class _SyncBatchNorm(torch.autograd.Function):
             dist.all_reduce(sums, group=ctx.group)
             n_total = rows * dist.get_world_size(ctx.group)
         dx = torch.empty_like(x)
-        rc = f_dx(dy.data_ptr(), x.data_ptr(), stat.data_ptr(), w.data_ptr(), b.data_ptr(), ctx.relu, sums.data_ptr(), n_total, rows, C,
+        rc = f_dx(dy.data_ptr(), x.data_ptr(), dt, stat.data_ptr(), w.data_ptr(), b.data_ptr(), ctx.relu, sums.data_ptr(), n_total, rows, C,
                   dx.data_ptr(), stream)
         if rc:
             _lib.check(rc, "md_bn_bwd_dx")
@@ -1110,9 +1117,9 @@ def sync_batch_norm(x, weight, bias, running_mean=None, running_var=None, moment
 def batch_norm_eval(x, weight, bias, running_mean, running_var, eps=1e-5, relu=False):
     """evaluation-mode BatchNorm [+ ReLU] from the running statistics, one kernel; no gradient"""
     with torch.no_grad():
-        x, rows, C = _rows_channels_last(x.float())
+        x, rows, C = _rows_channels_last(x)
         y = torch.empty_like(x)
-        _lib.call("md_bn_eval", _p(x), _p(running_mean.float()), _p(running_var.float()), float(eps), _p(weight.float().contiguous()),
+        _lib.call("md_bn_eval", _p(x), _BN_DTYPE[x.dtype], _p(running_mean.float()), _p(running_var.float()), float(eps), _p(weight.float().contiguous()),
                   _p(bias.float().contiguous()), int(relu), _p(y), rows, C, _stream())
     return y
 

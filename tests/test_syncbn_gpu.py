@@ -66,6 +66,70 @@ def test_sync_batch_norm_vs_torch_fp64(shape, stored_cl, relu):
     assert torch.equal(yc, ya)
 
 
+@pytest.mark.parametrize("relu", [False, True])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shape", [(3, 64, 24, 40), (2, 16, 5, 7, 9), (2, 8, 64, 128), (2, 512, 6, 20)])
+def test_sync_batch_norm_half_io_vs_torch_fp64(shape, dtype, relu):
+    """bf16 / fp16 activations and gradients (what torch.autocast hands a BatchNorm layer): the kernels read and write the 2-byte
+    type directly, statistics and parameter gradients in fp32 / double.  Reference: the same op in float64 ON THE ROUNDED INPUTS;
+    outputs within one rounding step of the 2-byte type (8 bits of mantissa for bf16, 11 for fp16), sums within 1e-4."""
+    from movedepth_amd import ops
+
+    torch.manual_seed(5)
+    C = shape[1]
+    x = (torch.randn(*shape, device="cuda") * 1.5 + 0.3).to(dtype).contiguous(memory_format=_fmt(shape))
+    gy = torch.randn(*shape, device="cuda").to(dtype)
+    gamma, beta = torch.rand(C, device="cuda") + 0.5, torch.randn(C, device="cuda") * 0.2
+    rm_a, rv_a = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
+    xa, ga, ba = x.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    ya = ops.sync_batch_norm(xa, ga, ba, rm_a, rv_a, 0.1, 1e-5, relu=relu)
+    assert ya.dtype is dtype and ya.shape == x.shape and ya.is_contiguous(memory_format=_fmt(shape))
+    ya.backward(gy)
+    assert xa.grad.dtype is dtype and ga.grad.dtype is torch.float32
+    xb, gb, bb = (t.double().clone().requires_grad_(True) for t in (x, gamma, beta))
+    rm_b, rv_b = torch.zeros(C, device="cuda", dtype=torch.float64), torch.ones(C, device="cuda", dtype=torch.float64)
+    yb = torch.nn.functional.batch_norm(xb, rm_b, rv_b, gb, bb, True, 0.1, 1e-5)
+    if relu:
+        yb = torch.relu(yb)
+    yb.backward(gy.double())
+    step = 2.0 ** -8 if dtype is torch.bfloat16 else 2.0 ** -11
+    n = x.numel() // C
+    # element-wise: |got - want| <= one rounding step of |want| (+ a floor for values near zero)
+    for got, want, what in ((ya, yb, "y"), (xa.grad, xb.grad, "d_x")):
+        g_, w_ = got.detach().double(), want.detach()
+        bad = (g_ - w_).abs() > step * w_.abs() + step * 1e-2 * float(w_.abs().max())
+        # a ReLU pre-activation within rounding of zero may fall on the other side in d_x
+        assert int(bad.sum()) <= (bad.numel() * 1e-4 if (relu and what == "d_x") else 0), (what, int(bad.sum()))
+    rt = 2e-3 if relu else 1e-4
+    assert_close(host(ga.grad), host(gb.grad), rtol=rt if n >= 100 else 5e-4, what="d_gamma")
+    assert_close(host(ba.grad), host(bb.grad), rtol=rt if n >= 100 else 5e-4, what="d_beta")
+    assert_close(host(rm_a), host(rm_b), rtol=1e-5, what="running_mean")
+    assert_close(host(rv_a), host(rv_b), rtol=1e-5, what="running_var")
+
+
+def test_autocast_step_keeps_batchnorm_in_half_precision():
+    """under torch.autocast a converted model's BatchNorm layers run on the 2-byte kernels: no float32 copies of the activations"""
+    import copy
+    from movedepth_amd import networks
+
+    torch.manual_seed(2)
+    ref = torch.nn.Sequential(torch.nn.Conv2d(3, 16, 3, padding=1, bias=False), torch.nn.BatchNorm2d(16), torch.nn.ReLU(),
+                              torch.nn.Conv2d(16, 8, 3, padding=1, bias=False), torch.nn.BatchNorm2d(8)).cuda().to(memory_format=torch.channels_last)
+    conv = networks.convert_hip_sync_batchnorm(copy.deepcopy(ref))
+    x = torch.randn(4, 3, 20, 24, device="cuda").contiguous(memory_format=torch.channels_last)
+    seen = []
+    conv[1].register_forward_hook(lambda m, i, o: seen.append((i[0].dtype, o.dtype)))
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        ya, yb = conv(x), ref(x)
+    assert seen == [(torch.bfloat16, torch.bfloat16)]
+    assert ya.dtype is yb.dtype
+    assert_close(host(ya), host(yb), rtol=3e-2, what="autocast forward")     # two bf16 pipelines: a few rounding steps apart
+    gw = torch.randn_like(ya, dtype=torch.float32)     # (a loss like mean(y^2) of a normalised output has no gradient to compare)
+    (ya.float() * gw).sum().backward()
+    (yb.float() * gw).sum().backward()
+    assert_close(host(conv[0].weight.grad), host(ref[0].weight.grad), rtol=5e-2, what="autocast d_weight")
+
+
 def test_eval_mode_and_state_dict_compat():
     from movedepth_amd import networks, ops
 
