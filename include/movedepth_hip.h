@@ -310,8 +310,10 @@ int md_bn_apply(const void *x, int dtype, const double *sums, long long n_total,
                 int C, md_stream_t stream);
 int md_bn_eval(const void *x, int dtype, const float *running_mean, const float *running_var, float eps, const float *gamma,
                const float *beta, int relu, void *y, long long nrows, int C, md_stream_t stream);
+/* sums_copy (may be NULL): a second copy of the 2C sums, for the caller to all-reduce in place while `sums` stays this rank's
+ * d_beta / d_gamma (ABI 15; saves a copy kernel per layer and step) */
 int md_bn_bwd_reduce(const void *dy, const void *x, int dtype, const float *stat, const float *gamma, const float *beta, int relu,
-                     long long nrows, int C, float *sums, void *ws, md_stream_t stream);
+                     long long nrows, int C, float *sums, float *sums_copy, void *ws, md_stream_t stream);
 int md_bn_bwd_dx(const void *dy, const void *x, int dtype, const float *stat, const float *gamma, const float *beta, int relu,
                  const float *sums, long long n_total, long long nrows, int C, void *dx, md_stream_t stream);
 

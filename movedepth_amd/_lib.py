@@ -78,7 +78,7 @@ SIGNATURES = {
     "md_bn_stats": (_i, [_vp, _i, _ll, _i, _vp, _vp, _vp]),
     "md_bn_apply": (_i, [_vp, _i, _vp, _ll, _f, _f, _vp, _vp, _i, _vp, _vp, _vp, _vp, _ll, _i, _vp]),
     "md_bn_eval": (_i, [_vp, _i, _vp, _vp, _f, _vp, _vp, _i, _vp, _ll, _i, _vp]),
-    "md_bn_bwd_reduce": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _ll, _i, _vp, _vp, _vp]),
+    "md_bn_bwd_reduce": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _ll, _i, _vp, _vp, _vp, _vp]),
     "md_bn_bwd_dx": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _ll, _ll, _i, _vp, _vp]),
     "md_pose_matrix_fwd": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "md_pose_matrix_bwd": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),

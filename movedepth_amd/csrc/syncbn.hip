@@ -100,7 +100,7 @@ __device__ __forceinline__ void st_piece(f16_t *p, long long i, float4 o) {
 // partial[blk][1][C] (b); then the ticket: the last block to arrive adds all partials in block order (double) into out[2C].
 template <typename OUT>
 __device__ __forceinline__ void bn_block_finish(float4 a, float4 b, int QN, float *__restrict__ partial, unsigned *__restrict__ counter,
-                                                OUT *__restrict__ out) {
+                                                OUT *__restrict__ out, OUT *__restrict__ out2 = nullptr) {
     extern __shared__ float4 sh[];   // [2][NT]
     __shared__ bool last;
     const int NT = blockDim.x, tid = threadIdx.x, C = 4 * QN;
@@ -176,6 +176,7 @@ __device__ __forceinline__ void bn_block_finish(float4 a, float4 b, int QN, floa
             double t = 0.0;
             for (int k = 0; k < nsh; ++k) t += shd[k * nout + tid];
             out[o0 + tid] = (OUT)t;
+            if (out2) out2[o0 + tid] = (OUT)t;   // a second copy for the caller to all-reduce in place (the first stays this rank's)
         }
     }
     if (tid == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch on this workspace
@@ -310,7 +311,7 @@ __global__ void bn_eval_kernel(const IO *__restrict__ x, BnGeo g, const float *_
 template <bool RELU, typename IO>
 __global__ void bn_bwd_reduce_kernel(const IO *__restrict__ dy, const IO *__restrict__ x, BnGeo g, const float *__restrict__ stat,
                                      const float *__restrict__ gamma, const float *__restrict__ beta, float *__restrict__ partial,
-                                     unsigned *__restrict__ counter, float *__restrict__ sums) {
+                                     unsigned *__restrict__ counter, float *__restrict__ sums, float *__restrict__ sums_copy) {
     const int q = (int)(((long long)blockIdx.x * blockDim.x + threadIdx.x) % g.QN);
     const BnQuad c = bn_quad_from_stat(stat, g.C, q, gamma, beta);
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f), sx = s;
@@ -334,7 +335,7 @@ __global__ void bn_bwd_reduce_kernel(const IO *__restrict__ dy, const IO *__rest
         acc(v1, g1);
     }
     for (; i < g.npieces; i += stride) acc(ld_stream(x, i), ld_stream(dy, i));
-    bn_block_finish<float>(s, sx, g.QN, partial, counter, sums);
+    bn_block_finish<float>(s, sx, g.QN, partial, counter, sums, sums_copy);
 }
 
 template <bool RELU, typename IO>
@@ -439,7 +440,7 @@ int md_bn_eval(const void *x, int dtype, const float *running_mean, const float 
 }
 
 int md_bn_bwd_reduce(const void *dy, const void *x, int dtype, const float *stat, const float *gamma, const float *beta, int relu,
-                     long long nrows, int C, float *sums, void *ws, md_stream_t stream) {
+                     long long nrows, int C, float *sums, float *sums_copy, void *ws, md_stream_t stream) {
     MD_REQUIRE(dy && x && stat && gamma && beta && sums && ws, "md_bn_bwd_reduce: null tensor argument");
     BnGeo g;
     if (int rc = bn_args("md_bn_bwd_reduce", nrows, C, g)) return rc;
@@ -447,9 +448,9 @@ int md_bn_bwd_reduce(const void *dy, const void *x, int dtype, const float *stat
     float *partial = (float *)((char *)ws + 256);
     const size_t lds = 2 * g.NTR * sizeof(float4);
     if (relu) { BN_BY_DTYPE("md_bn_bwd_reduce", dtype, MD_LAUNCH_TIMED("md_bn_bwd_reduce", (bn_bwd_reduce_kernel<true, IO>), dim3(g.nblk), dim3(g.NTR), lds, (hipStream_t)stream,
-                                                                       (const IO *)dy, (const IO *)x, g, stat, gamma, beta, partial, counter, sums)) }
+                                                                       (const IO *)dy, (const IO *)x, g, stat, gamma, beta, partial, counter, sums, sums_copy)) }
     else { BN_BY_DTYPE("md_bn_bwd_reduce", dtype, MD_LAUNCH_TIMED("md_bn_bwd_reduce", (bn_bwd_reduce_kernel<false, IO>), dim3(g.nblk), dim3(g.NTR), lds, (hipStream_t)stream,
-                                                                  (const IO *)dy, (const IO *)x, g, stat, gamma, beta, partial, counter, sums)) }
+                                                                  (const IO *)dy, (const IO *)x, g, stat, gamma, beta, partial, counter, sums, sums_copy)) }
     MD_CHECK_LAUNCH("md_bn_bwd_reduce");
     return MD_OK;
 }

@@ -931,8 +931,8 @@ class _BnRelu3d(torch.autograd.Function):
         _timed_call("md_bn_relu_stats", _p(x), nvox, C, _p(sums), _p(ws), _stream())
         n_total = nvox
         if group is not None:
-            dist.all_reduce(sums, group=group)
-            n_total = nvox * dist.get_world_size(group)
+            _group_all_reduce(sums, group)
+            n_total = nvox * _group_size(group)
         stat = torch.empty(2 * C, device=x.device, dtype=torch.float32)
         mean, invstd = stat[:C], stat[C:]
         rm = running_mean if (running_mean is not None and running_mean.dtype == torch.float32) else None
@@ -962,8 +962,8 @@ class _BnRelu3d(torch.autograd.Function):
         if ctx.group is not None:
             local = sums
             sums = local.clone()
-            dist.all_reduce(sums, group=ctx.group)
-            n_total = nvox * dist.get_world_size(ctx.group)
+            _group_all_reduce(sums, ctx.group)
+            n_total = nvox * _group_size(ctx.group)
         dx = torch.empty_like(x, memory_format=torch.channels_last_3d)
         _timed_call("md_bn_relu_bwd_dx", _p(dy), _p(x), _p(mean), _p(invstd), _p(w), _p(b), _p(sums), n_total, nvox, C, _p(dx),
                     _stream())
@@ -1007,6 +1007,22 @@ def _bn_ws(device, stream):
         t = torch.zeros(int(_lib.load().md_bn_ws_bytes()), dtype=torch.uint8, device=device)
         ws = _BN_WS[key] = (t, t.data_ptr())
     return ws[1]
+
+
+def _group_all_reduce(t, group):
+    """in-place sum over `group`: a rccl_direct.DirectAllReduce (RCCL on the current stream) or a torch.distributed group"""
+    if callable(group):
+        group(t)
+    else:
+        import torch.distributed as dist
+        dist.all_reduce(t, group=group)
+
+
+def _group_size(group):
+    if callable(group):
+        return group.size
+    import torch.distributed as dist
+    return dist.get_world_size(group)
 
 
 _BN_DTYPE = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}   # `dtype` of md_bn_* (include/movedepth_hip.h)
@@ -1058,8 +1074,8 @@ class _SyncBatchNorm(torch.autograd.Function):
         if group is not None:
             import torch.distributed as dist
             # every rank contributes the same number of rows (the per-GPU batch is fixed: the loaders drop the last batch)
-            dist.all_reduce(sums, group=group)
-            n_total = rows * dist.get_world_size(group)
+            _group_all_reduce(sums, group)
+            n_total = rows * _group_size(group)
         y = torch.empty_like(x)   # preserves the channels-last strides
         w, b = _f32c(weight), _f32c(bias)
         rm = running_mean.data_ptr() if (running_mean is not None and running_mean.dtype is torch.float32) else None
@@ -1080,18 +1096,23 @@ class _SyncBatchNorm(torch.autograd.Function):
         dev = x.device
         stream = torch._C._cuda_getCurrentRawStream(dev.index)
         _, _, f_reduce, f_dx = _bn_fns()
-        sums = torch.empty(2 * C, device=dev, dtype=torch.float32)
+        # 2C sums of this rank (= d_beta, d_gamma: the gradient reducer averages parameter gradients) and, in a group, a second
+        # copy written by the same kernel for the all-reduce
+        grouped = ctx.group is not None
+        buf = torch.empty(4 * C if grouped else 2 * C, device=dev, dtype=torch.float32)
+        sums = buf[:2 * C]
+        gsums = buf[2 * C:] if grouped else sums
         rc = f_reduce(dy.data_ptr(), x.data_ptr(), dt, stat.data_ptr(), w.data_ptr(), b.data_ptr(), ctx.relu, rows, C, sums.data_ptr(),
-                      _bn_ws(dev, stream), stream)
+                      gsums.data_ptr() if grouped else None, _bn_ws(dev, stream), stream)
         if rc:
             _lib.check(rc, "md_bn_bwd_reduce")
-        d_beta, d_gamma = sums[:C], sums[C:]          # this rank's sums (the gradient reducer averages parameter gradients)
+        d_beta, d_gamma = sums[:C], sums[C:]
         n_total = rows
-        if ctx.group is not None:
+        if grouped:
             import torch.distributed as dist
-            sums = sums.clone()
-            dist.all_reduce(sums, group=ctx.group)
-            n_total = rows * dist.get_world_size(ctx.group)
+            _group_all_reduce(gsums, ctx.group)
+            n_total = rows * _group_size(ctx.group)
+        sums = gsums
         dx = torch.empty_like(x)
         rc = f_dx(dy.data_ptr(), x.data_ptr(), dt, stat.data_ptr(), w.data_ptr(), b.data_ptr(), ctx.relu, sums.data_ptr(), n_total, rows, C,
                   dx.data_ptr(), stream)

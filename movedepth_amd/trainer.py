@@ -102,13 +102,20 @@ class Trainer:
             self.vol_layout = "ndhwc"
         if opt.vol_layout != "auto":
             self.vol_layout = opt.vol_layout
+        # the statistics all-reduces of the synchronised BatchNorm layers: straight to RCCL on the compute stream through a
+        # communicator of their own when the backend is nccl (rccl_direct: no cross-stream hops, 2 ms per step), else torch's group
+        bn_group = None
+        if opt.ddp and opt.sync_bn:
+            from . import rccl_direct
+            bn_group = (rccl_direct.make(None) if opt.sync_bn_impl == "hip" else None) or dist.group.WORLD
+        self.bn_group = bn_group
         for k, m in self.models.items():
             if opt.sync_bn and (opt.ddp or opt.force_sync_bn):   # also with MD_SHARE_GPU=1: over gloo on CUDA tensors
                 if opt.sync_bn_impl == "hip":
                     # every BatchNorm on the kernels of csrc/syncbn.hip: statistics over the global batch, one all-reduce of 2C
                     # sums per layer and direction (torch's SyncBatchNorm is built from its native batch-norm kernels, which
                     # cost a rank 14 % of a step before any collective: DESIGN 6)
-                    m = networks.convert_hip_sync_batchnorm(m, dist.group.WORLD if opt.ddp else None,
+                    m = networks.convert_hip_sync_batchnorm(m, bn_group if opt.ddp else None,
                                                             fuse_relu=os.environ.get("MD_HIPBN_FUSE_RELU", "1") == "1")
                 elif opt.ddp:
                     m = torch.nn.SyncBatchNorm.convert_sync_batchnorm(m)
@@ -121,7 +128,7 @@ class Trainer:
             for mod in m.modules():
                 if isinstance(mod, networks.FusedBNReLU3d):
                     if opt.ddp and opt.sync_bn:   # what convert_sync_batchnorm does for the others
-                        mod.sync_group = dist.group.WORLD
+                        mod.sync_group = bn_group
         if opt.bn_counter_on_host:
             # BatchNorm's num_batches_tracked += 1 is a GPU kernel per BatchNorm call (115 per step, ~0.5 ms) for a counter
             # nothing on the device reads (momentum is fixed): keep the counters in host memory.  Same state_dict.
