@@ -98,3 +98,53 @@ def test_gradsync_single_process_is_identity():
     net.bias.grad = None
     net(x).sum().backward()
     assert torch.allclose(g, net.weight.grad)
+
+
+def _worker_unused(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from movedepth_amd.dp import GradSync
+
+    torch.manual_seed(7)   # same weights on every rank
+    used, unused = torch.nn.Linear(6, 4), torch.nn.Linear(6, 4)
+    params = list(used.parameters()) + list(unused.parameters())
+    sync = GradSync(params, bucket_mb=1e-5)   # one bucket per tensor: some complete in the hooks, the unused ones only in finish()
+    out = []
+    for step in range(2):
+        x = torch.full((3, 6), float(rank + 1 + step))
+        sync.zero_grad()
+        assert all(p.grad is None for p in params)            # nothing pre-filled: autograd assigns, the hook packs
+        used(x).sum().backward()
+        sync.finish()
+        assert all(p.grad is not None for p in params)
+        # .grad are views into the flat buckets after the step
+        assert all(p.grad.data_ptr() == v.data_ptr() for vs, (_, ps) in zip(sync.views, sync.buckets) for p, v in zip(ps, vs))
+        out.append([p.grad.clone().numpy() for p in params])
+    q.put((rank, out, len(sync.buckets)))
+    dist.destroy_process_group()
+
+
+def test_gradsync_packs_buckets_and_zeroes_unused_parameters():
+    """the packed-bucket reducer: gradients of parameters that took part are the mean over ranks, parameters of an unused branch get
+    zeros (and still take part in the collective: every rank issues the same all-reduces), two steps in a row"""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_unused, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    import numpy as np
+
+    (_, ga, nb), (_, gb, _) = res
+    assert nb == 4
+    for step in range(2):
+        for a, b in zip(ga[step], gb[step]):
+            assert np.array_equal(a, b)
+        # d/dW of sum(W x + b) = x summed over the 3 rows, mean over ranks: 3 * mean(rank + 1 + step) = 3 * (1.5 + step); d/db = 3
+        assert np.allclose(ga[step][0], 3.0 * (1.5 + step)) and np.allclose(ga[step][1], 3.0)
+        assert not ga[step][2].any() and not ga[step][3].any()
