@@ -135,6 +135,27 @@ def test_warp(oracle_lib, tag):
     assert_close(d_T, g["d_T"], rtol=2e-4, what="d_T")
 
 
+def test_warp_fullres_reference_fixture(oracle_lib):
+    """192 x 640: the reference's own warp + autograd (tools/gen_golden.py gen_warp_fullres) on inputs rebuilt from a seed
+    (tests/golden_inputs.py); the fixture keeps the small outputs.  Sample grid and warped frame: the stored samples bit-equal, the
+    row sums equal to float64 rounding; pose gradient within north_star's 1e-4."""
+    from golden_inputs import warp_fullres_inputs
+    g = load_golden("warp_fullres")
+    img, depth, gout = warp_fullres_inputs()
+    out, pix = oracle_lib.warp(img, depth, g["K"], g["invK"], g["T"])
+    assert np.array_equal(pix[:, ::16, ::16], g["pix_sample"]) and np.array_equal(out[:, :, ::16, ::16], g["warped_sample"])
+    assert np.allclose(pix.astype(np.float64).sum(2), g["pix_rowsum"], rtol=0, atol=1e-9)       # equal addends, float64 sums
+    assert np.allclose(out.astype(np.float64).sum(-1), g["warped_rowsum"], rtol=0, atol=1e-9)
+    assert int((((pix < -1) | (pix > 1)).sum(-1) > 0).sum()) == int(g["mask_count"])
+    assert abs(float((out.astype(np.float64) * gout).sum()) - float(g["loss"])) <= 1e-6 * abs(float(g["loss"]))
+    d_depth, d_T = oracle_lib.warp_bwd(gout, img, depth, g["K"], g["invK"], g["T"])
+    d_depth = d_depth.reshape(depth.shape)
+    assert_close(d_T, g["d_T"], rtol=1e-4, what="d_T")
+    assert_close(d_depth[:, :, ::16, ::16], g["d_depth_sample"], rtol=2e-4, atol_scale=5e-3, what="d_depth samples")
+    err = np.abs(d_depth.astype(np.float64).sum(-1) - g["d_depth_rowsum"])
+    assert float(err.max()) <= 2e-4 * float(g["d_depth_abs_rowsum"].max()), float(err.max())
+
+
 def test_ssim_and_reprojection_loss(oracle_lib):
     g = load_golden("ssim")
     assert_close(oracle_lib.ssim(g["pred"], g["target"]), g["ssim"], what="ssim map")

