@@ -27,3 +27,32 @@ def warp_fullres_inputs(seed=11, B=2, H=192, W=640):
     depth = bilinear_field(rng, (B, 1, H, W), 16, 2.0, 22.0)
     gout = bilinear_field(rng, (B, 3, H, W), 8, 0.2, 1.0)
     return img, depth, gout
+
+
+def costvol_launch_inputs(seed=12, B=6, C=32, G=16, h=48, w=160, D=96):
+    """reference / source feature maps, depth prior and upstream gradient of the plane-sweep fixture at BASELINE config 2's launch
+    shape (tests/golden/costvol_launch.npz holds K, inv_K, pose and the reference's small outputs).  The upstream gradient of the
+    (B, D, G, h, w) volume is an outer product of two small random tensors: one rounded float32 multiplication per element."""
+    rng = np.random.default_rng(seed)
+    ref = bilinear_field(rng, (B, C, h, w), 3, -1.0, 1.0)
+    src = bilinear_field(rng, (B, C, h, w), 3, -1.0, 1.0)
+    prior = bilinear_field(rng, (B, 1, h, w), 8, 2.0, 22.0)
+    a = rng.standard_normal((B, D, G)).astype(np.float32)
+    sp = (0.5 + rng.random((B, h, w))).astype(np.float32)
+    gout = a[:, :, :, None, None] * sp[:, None, None, :, :]
+    return ref, src, prior, gout
+
+
+def check_costvol_launch(g, vol, d_ref, d_src, rtol=1e-4):
+    """vol (B, D, G, h, w), d_ref / d_src (B, C, h, w) as numpy arrays against tests/golden/costvol_launch.npz `g`: plane sums within
+    rtol of the planes' absolute sums, lattice values within rtol norm-wise.  Returns the worst ratios for printing."""
+    worst = {}
+    for name, t, lat in (("vol", vol, vol[:, ::8, ::2, ::8, ::16]), ("d_ref", d_ref, d_ref[..., ::8, ::16]), ("d_src", d_src, d_src[..., ::8, ::16])):
+        s = t.astype(np.float64).sum((-1, -2))
+        r = float((np.abs(s - g[name + "_sum"]) / np.maximum(g[name + "_abs_sum"], 1e-30)).max())
+        want = g[name + "_lattice"].astype(np.float64)
+        n = float(np.linalg.norm(lat.astype(np.float64) - want) / np.linalg.norm(want))
+        worst[name] = (r, n)
+        assert r <= rtol, "%s: a plane sum differs from the reference's by %.2e of the plane's absolute sum" % (name, r)
+        assert n <= rtol, "%s: lattice values differ from the reference's by %.2e (norm-wise)" % (name, n)
+    return worst

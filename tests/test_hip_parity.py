@@ -237,6 +237,21 @@ def test_costvol_config2_launch_shape_vs_oracle(ops, oracle_lib, prior_kind, fea
 
 
 @pytest.mark.parametrize("feat", FEATS)
+def test_costvol_config2_launch_shape_reference_fixture(ops, feat):
+    """The same launch against the REFERENCE's own generate_costvol + group mean + autograd (tests/golden/costvol_launch.npz from
+    tools/gen_golden.py gen_costvol_launch: plane sums and a lattice of the volume and of both feature gradients; the large inputs
+    are rebuilt from a seed by tests/golden_inputs.py).  Reference: layers.py:778-794, trainer.py:351-363."""
+    from golden_inputs import check_costvol_launch, costvol_launch_inputs
+    g = load_golden("costvol_launch")
+    ref, src, prior, gout = costvol_launch_inputs()
+    r, s = feat_dev(ref, feat), feat_dev(src, feat)
+    vol = ops.costvol_grouped(r, s, dev(g["K"]), dev(g["invK"]), dev(g["pose"][:, 0]), int(g["G"]), prior=dev(prior), ndepth=96,
+                              scale_fac=0.3, z_trans=None, type="inverse", layout="ndhwc")
+    vol.backward(dev(gout))
+    print("config-2 launch shape vs the reference's fixture (plane-sum ratio, lattice rel):", check_costvol_launch(g, host(vol), host(r.grad), host(s.grad)))
+
+
+@pytest.mark.parametrize("feat", FEATS)
 @pytest.mark.parametrize("C,B,dtype", [(32, 6, torch.bfloat16), (64, 3, torch.bfloat16), (64, 4, torch.float32)])
 def test_costvol_config4_launch_shapes_vs_oracle(ops, oracle_lib, C, B, dtype, feat):
     """BASELINE config 4's volume (80x256 features, D=128) against the oracle at the batch sizes whose launches take the

@@ -135,6 +135,19 @@ def test_warp(oracle_lib, tag):
     assert_close(d_T, g["d_T"], rtol=2e-4, what="d_T")
 
 
+def test_costvol_launch_shape_reference_fixture(oracle_lib):
+    """BASELINE config 2's launch shape (B=6, C=32, G=16, 48x160, D=96) against the REFERENCE's own generate_costvol + group mean +
+    autograd (tools/gen_golden.py gen_costvol_launch; large tensors rebuilt from a seed, the fixture keeps plane sums and a lattice)."""
+    from golden_inputs import check_costvol_launch, costvol_launch_inputs
+    g = load_golden("costvol_launch")
+    ref, src, prior, gout = costvol_launch_inputs()
+    hyp = oracle_lib.schedule_depth_range(prior, 96, 0.3, None, "inverse")
+    pose = g["pose"][:, 0]
+    vol = oracle_lib.costvol_grouped(ref, src, g["K"], g["invK"], hyp, pose, int(g["G"]))
+    d_ref, d_src = oracle_lib.costvol_grouped_bwd(gout, ref, src, g["K"], g["invK"], hyp, pose)
+    print(check_costvol_launch(g, vol, d_ref, d_src))
+
+
 def test_warp_fullres_reference_fixture(oracle_lib):
     """192 x 640: the reference's own warp + autograd (tools/gen_golden.py gen_warp_fullres) on inputs rebuilt from a seed
     (tests/golden_inputs.py); the fixture keeps the small outputs.  Sample grid and warped frame: the stored samples bit-equal, the

@@ -181,6 +181,32 @@ def gen_costvol(L):
     case("c64g8", 206, B=1, C=64, G=8, h=6, w=10, D=5, rot=0.02, trans=0.1, tz=None)
 
 
+def gen_costvol_launch(L):
+    """generate_costvol + the group mean at the launch shape bench.py and the trainer run (BASELINE config 2: B=6, C=32, G=16, 48x160,
+    D=96), with autograd, from the reference's own code.  Large tensors are rebuilt from a seed (tests/golden_inputs.py); the
+    fixture keeps K, inv_K, the poses and small outputs: per-(b, d, g) plane sums and absolute sums of the grouped volume (float64),
+    a lattice of its values, per-(b, c) sums / absolute sums and a lattice of d_ref and d_src."""
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tests"))
+    from golden_inputs import costvol_launch_inputs
+    B, C, G, h, w, D = 6, 32, 16, 48, 160, 96
+    ref, src, prior, gout = (torch.from_numpy(a) for a in costvol_launch_inputs(12, B, C, G, h, w, D))
+    K, invK = kitti_K(h, w, B)
+    g = torch.Generator().manual_seed(312)
+    pose = poses(L, B, g, rot=0.01, trans=0.05)[2].unsqueeze(1)   # B 1 4 4
+    hyp = L.schedule_depth_rangev2(prior, D, 0.3, type="inverse")
+    ref.requires_grad_(True)
+    src.requires_grad_(True)
+    bp, pj = L.BackprojectDepth(D, h, w), L.Project3D(D, h, w)
+    cv = L.generate_costvol(ref, src, K, invK, hyp, pose, D, bp, pj)          # B D C h w
+    cor = cv.reshape(B, D, -1, G, h, w).mean(2)                                # trainer.py:358-359, one lookup frame
+    (cor * gout).sum().backward()
+    lat = lambda t: t[..., ::8, ::16]
+    save("costvol_launch", dict(K=K, invK=invK, pose=pose, G=G,
+                                vol_sum=cor.double().sum((-1, -2)), vol_abs_sum=cor.double().abs().sum((-1, -2)), vol_lattice=lat(cor)[:, ::8, ::2],
+                                d_ref_sum=ref.grad.double().sum((-1, -2)), d_ref_abs_sum=ref.grad.double().abs().sum((-1, -2)), d_ref_lattice=lat(ref.grad),
+                                d_src_sum=src.grad.double().sum((-1, -2)), d_src_abs_sum=src.grad.double().abs().sum((-1, -2)), d_src_lattice=lat(src.grad)))
+
+
 def gen_warp(L):
     def case(tag, seed, rot, trans):
         g = torch.Generator().manual_seed(seed)
@@ -505,6 +531,7 @@ def main():
     gen_geometry(L)
     gen_schedule(L)
     gen_costvol(L)
+    gen_costvol_launch(L)
     gen_warp(L)
     gen_warp_fullres(L)
     gen_ssim(L, Trainer)
