@@ -30,7 +30,11 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(const float *__restrict__
     if (row0 >= H) return;
     const size_t HW = (size_t)H * W;
     const float *xb = X + (size_t)b * C * HW, *yb = Y + (size_t)b * C * HW;
-    float xv[3][C], yv[3][C];
+    // rows roll through registers together with their left / right neighbours (wave shuffles), so that the nine taps of a window
+    // are added ONE BY ONE in the reference's order -- AvgPool2d walks the window row-major and adds already-rounded products
+    // (layers.py:663-671).  sigma = E[x^2] - mu^2 cancels to 1e-3 of its terms on smooth images: with the columns summed first
+    // (the first version of this kernel) the loss of a 192 x 640 step sat 4e-4 from the reference's.  No contraction below.
+    float xv[3][C], yv[3][C], xl[3][C], xg[3][C], yl[3][C], yg[3][C];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
         const int rr = clampi(reflect1(row0 - 1 + s, H), 0, H - 1);
@@ -38,6 +42,8 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(const float *__restrict__
         for (int c = 0; c < C; ++c) {
             xv[s][c] = xb[c * HW + (size_t)rr * W + xr];
             yv[s][c] = yb[c * HW + (size_t)rr * W + xr];
+            xl[s][c] = __shfl_up(xv[s][c], 1, 64); xg[s][c] = __shfl_down(xv[s][c], 1, 64);
+            yl[s][c] = __shfl_up(yv[s][c], 1, 64); yg[s][c] = __shfl_down(yv[s][c], 1, 64);
         }
     }
     const bool writer = lane >= 1 && lane <= 62 && xcol < W;
@@ -50,16 +56,26 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(const float *__restrict__
         for (int c = 0; c < C; ++c) {
             xv[2][c] = xb[c * HW + (size_t)rr * W + xr];
             yv[2][c] = yb[c * HW + (size_t)rr * W + xr];
+            xl[2][c] = __shfl_up(xv[2][c], 1, 64); xg[2][c] = __shfl_down(xv[2][c], 1, 64);
+            yl[2][c] = __shfl_up(yv[2][c], 1, 64); yg[2][c] = __shfl_down(yv[2][c], 1, 64);
         }
         float l1 = 0.f, ss = 0.f;
 #pragma unroll
         for (int c = 0; c < C; ++c) {
-            Moments m;
-            m.mux = hsum3(xv[0][c] + xv[1][c] + xv[2][c]) / 9.f;
-            m.muy = hsum3(yv[0][c] + yv[1][c] + yv[2][c]) / 9.f;
-            m.ex2 = hsum3(xv[0][c] * xv[0][c] + xv[1][c] * xv[1][c] + xv[2][c] * xv[2][c]) / 9.f;
-            m.ey2 = hsum3(yv[0][c] * yv[0][c] + yv[1][c] * yv[1][c] + yv[2][c] * yv[2][c]) / 9.f;
-            m.exy = hsum3(xv[0][c] * yv[0][c] + xv[1][c] * yv[1][c] + xv[2][c] * yv[2][c]) / 9.f;
+            Moments m = {0.f, 0.f, 0.f, 0.f, 0.f};
+            {
+#pragma clang fp contract(off)
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) {
+                    const float xa[3] = {xl[dy][c], xv[dy][c], xg[dy][c]}, ya[3] = {yl[dy][c], yv[dy][c], yg[dy][c]};
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) {
+                        const float xx = xa[dx] * xa[dx], yy = ya[dx] * ya[dx], xy = xa[dx] * ya[dx];
+                        m.mux += xa[dx]; m.muy += ya[dx]; m.ex2 += xx; m.ey2 += yy; m.exy += xy;
+                    }
+                }
+                m.mux /= 9.f; m.muy /= 9.f; m.ex2 /= 9.f; m.ey2 /= 9.f; m.exy /= 9.f;
+            }
             float s = ssim_from(m, nullptr, nullptr);
             s = fminf(fmaxf(s, 0.f), 1.f);  // torch.clamp(., 0, 1)
             if (MODE == 0) {
@@ -76,8 +92,8 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(const float *__restrict__
         }
 #pragma unroll
         for (int c = 0; c < C; ++c) {
-            xv[0][c] = xv[1][c]; xv[1][c] = xv[2][c];
-            yv[0][c] = yv[1][c]; yv[1][c] = yv[2][c];
+            xv[0][c] = xv[1][c]; xv[1][c] = xv[2][c]; xl[0][c] = xl[1][c]; xl[1][c] = xl[2][c]; xg[0][c] = xg[1][c]; xg[1][c] = xg[2][c];
+            yv[0][c] = yv[1][c]; yv[1][c] = yv[2][c]; yl[0][c] = yl[1][c]; yl[1][c] = yl[2][c]; yg[0][c] = yg[1][c]; yg[1][c] = yg[2][c];
         }
     }
 }
@@ -118,14 +134,18 @@ __global__ __launch_bounds__(256) void reproj_bwd_kernel(const float *__restrict
                 float A = 0.f, Bc = 0.f, Cc = 0.f;
                 if (py >= 0 && py < H && px >= 0 && px < W) {
                     Moments m = {0.f, 0.f, 0.f, 0.f, 0.f};
+                    {
+#pragma clang fp contract(off)   // the forward's (= the reference's) window sums: rounded products added one by one
 #pragma unroll
-                    for (int dy = 0; dy < 3; ++dy)
+                        for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-                        for (int dx = 0; dx < 3; ++dx) {
-                            const float a = xs[(cy + dy) * IW + cx + dx], bb = ys[(cy + dy) * IW + cx + dx];
-                            m.mux += a; m.muy += bb; m.ex2 += a * a; m.ey2 += bb * bb; m.exy += a * bb;
-                        }
-                    m.mux /= 9.f; m.muy /= 9.f; m.ex2 /= 9.f; m.ey2 /= 9.f; m.exy /= 9.f;
+                            for (int dx = 0; dx < 3; ++dx) {
+                                const float a = xs[(cy + dy) * IW + cx + dx], bb = ys[(cy + dy) * IW + cx + dx];
+                                const float aa = a * a, b2 = bb * bb, ab = a * bb;
+                                m.mux += a; m.muy += bb; m.ex2 += aa; m.ey2 += b2; m.exy += ab;
+                            }
+                        m.mux /= 9.f; m.muy /= 9.f; m.ex2 /= 9.f; m.ey2 /= 9.f; m.exy /= 9.f;
+                    }
                     float n, d;
                     const float raw = ssim_from(m, &n, &d);
                     if (raw >= 0.f && raw <= 1.f) {  // clamp passes gradient only inside [0,1]

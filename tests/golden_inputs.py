@@ -56,3 +56,22 @@ def check_costvol_launch(g, vol, d_ref, d_src, rtol=1e-4):
         assert r <= rtol, "%s: a plane sum differs from the reference's by %.2e of the plane's absolute sum" % (name, r)
         assert n <= rtol, "%s: lattice values differ from the reference's by %.2e (norm-wise)" % (name, n)
     return worst
+
+
+def losses_fullres_inputs(seed=13, B=2, H=192, W=640):
+    """colour pyramids of the three frames (scale s = 2^s x 2^s block means of scale 0, float64 sums rounded once) and the four
+    disparity maps of the full-resolution photometric fixture (tests/golden/losses_mono_fullres.npz).  -> ({(f, s): image}, {s: disp})"""
+    rng = np.random.default_rng(seed)
+    colors = {}
+    for f in (0, -1, 1):
+        base = bilinear_field(rng, (B, 3, H, W), 6).astype(np.float64)
+        # a common structure so that the frames resemble each other (a photometric loss of unrelated images has no useful minimum)
+        if f == 0:
+            common = base
+        else:
+            base = 0.8 * common + 0.2 * base
+        for s in range(4):
+            k = 2 ** s
+            colors[(f, s)] = np.ascontiguousarray(base.reshape(B, 3, H // k, k, W // k, k).mean((3, 5)), dtype=np.float32)
+    disps = {s: (0.004 + 0.1 * bilinear_field(rng, (B, 1, H // 2 ** s, W // 2 ** s), 8).astype(np.float64)).astype(np.float32) for s in range(4)}
+    return colors, disps

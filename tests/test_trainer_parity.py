@@ -89,6 +89,65 @@ def test_mono_losses_match_reference(fused):
 
 
 @pytest.mark.parametrize("fused", [1, 0])
+def test_mono_losses_fullres_match_reference(fused):
+    """192 x 640, the size bench.py runs: the reference Trainer's own generate_images_pred + compute_losses + backward
+    (tests/golden/losses_mono_fullres.npz, tools/gen_golden.py gen_losses_fullres; images and disparities rebuilt from a seed by
+    tests/golden_inputs.py, the fixture keeps losses, pose gradients, row sums and lattices).  Losses and gradients within 1e-4;
+    the depth lattice bit-equal at scale 0 and within a few ulp at the up-sampled scales, sample grid and warped frames within 2e-6 / 1e-5 (the
+    reference's CPU F.interpolate sums its four taps in another order on 640-wide rows than on the small fixtures' rows, where the
+    kernels reproduce it bit for bit: the last bit of an up-sampled disparity differs in places)."""
+    from golden_inputs import losses_fullres_inputs
+    from movedepth_amd.layers import transformation_from_parameters
+
+    g = load_golden("losses_mono_fullres")
+    colors, disps_np = losses_fullres_inputs()
+    t = make_trainer(fused_photometric=fused, height=192, width=640)
+    inputs = {}
+    for (f, s), v in colors.items():
+        inputs[("color", f, s)] = dev(v)
+    for s in range(4):
+        inputs[("K", s)], inputs[("inv_K", s)] = dev(g["K_%d" % s]), dev(g["inv_K_%d" % s])
+    disps = {s: dev(disps_np[s], True) for s in range(4)}
+    aa = {-1: dev(g["axisangle_m1"], True), 1: dev(g["axisangle_p1"], True)}
+    tr = {-1: dev(g["translation_m1"], True), 1: dev(g["translation_p1"], True)}
+    outputs = {("disp", s): disps[s] for s in range(4)}
+    for f in (-1, 1):
+        outputs[("cam_T_cam", 0, f)] = transformation_from_parameters(aa[f], tr[f], invert=(f < 0))
+        assert_close(host(outputs[("cam_T_cam", 0, f)]), g["T_m1" if f < 0 else "T_p1"], rtol=1e-6)
+    torch.manual_seed(int(g["noise_seed"]))
+    t.generate_images_pred(inputs, outputs)
+    lat = lambda x: x[..., ::8, ::16]
+    for s in range(4):
+        got, want = lat(host(outputs[("depth", 0, s)])), g["depth_lattice_%d" % s]
+        assert np.array_equal(got, want) if s == 0 else float(np.abs(got / want - 1).max()) <= 4e-7, "depth lattice, scale %d" % s
+    for f, n in ((-1, "m1"), (1, "p1")):
+        for s in (0, 3):
+            gs, ws = host(outputs[("sample", f, s)])[:, ::8, ::16], g["sample_lattice_%s_%d" % (n, s)]
+            gc, wc = lat(host(outputs[("color", f, s)])), g["color_lattice_%s_%d" % (n, s)]
+            # (not bit-equal even at scale 0: T comes from the pose kernel's own sin / cos here, equal to the reference's to 1e-6;
+            # with T given, tests/test_hip_parity.py test_warp_fullres_reference_fixture holds grid and frame to the bit)
+            assert float(np.abs(gs - ws).max()) <= 2e-6 and relerr(gc, wc) <= 1e-5, "sample grid / warped frame %s scale %d" % (n, s)
+    losses = t.compute_losses(inputs, outputs)
+    for s in range(4):
+        assert abs(float(losses["loss/%d" % s]) - float(g["loss_%d" % s])) < 1e-4 * float(g["loss_%d" % s])
+        assert abs(float(losses["mono_smooth_loss/%d" % s]) - float(g["smooth_%d" % s])) < 1e-4 * float(g["smooth_%d" % s])
+    assert abs(float(losses["loss"]) - float(g["loss"])) < 1e-4 * float(g["loss"])
+    mr = host(outputs["mono_reproj_loss"])
+    assert_close(lat(mr), g["mono_reproj_lattice"], what="per-pixel minimum loss")
+    assert abs(float(mr.astype(np.float64).sum()) - float(g["mono_reproj_sum"])) < 1e-5 * float(g["mono_reproj_sum"])
+    losses["loss"].backward()
+    for s in range(4):
+        dd = host(disps[s].grad)
+        err = np.abs(dd.astype(np.float64).sum(-1) - g["d_disp_rowsum_%d" % s])
+        assert float(err.max()) <= 1e-4 * float(g["d_disp_abs_rowsum_%d" % s].max()), (s, float(err.max()))
+        assert_close_knife_edge(dd[..., ::4, ::8], g["d_disp_lattice_%d" % s], rtol=2e-4, what="d_disp_%d lattice" % s)
+    for f, n in ((-1, "m1"), (1, "p1")):
+        print("fullres pose gradient rel err", n, relerr(host(aa[f].grad), g["d_axisangle_" + n]), relerr(host(tr[f].grad), g["d_translation_" + n]))
+        assert_close(host(aa[f].grad), g["d_axisangle_" + n], rtol=1e-4, what="d_axisangle")
+        assert_close(host(tr[f].grad), g["d_translation_" + n], rtol=1e-4, what="d_translation")
+
+
+@pytest.mark.parametrize("fused", [1, 0])
 def test_mono_losses_without_automask(fused):
     g, gm = load_golden("losses_mono_noautomask"), load_golden("losses_mono")
     t = make_trainer(disable_automasking=True, fused_photometric=fused)

@@ -428,6 +428,53 @@ def gen_losses(L, Trainer):
         save("losses_mvs_" + tag, d3)
 
 
+def gen_losses_fullres(L, Trainer):
+    """generate_images_pred + compute_losses + backward of the reference's own Trainer at 192 x 640 (the size bench.py runs), B = 2,
+    mono branch with auto-masking.  Images and disparities are rebuilt from a seed (tests/golden_inputs.py); the fixture keeps the
+    pose parameters and small outputs: losses, pose gradients, row sums / absolute row sums and a lattice of the disparity
+    gradients, lattices of depth, sample grid, warped frames and of the per-pixel minimum loss."""
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tests"))
+    from golden_inputs import losses_fullres_inputs
+    B, H, W = 2, 192, 640
+    colors, disps_np = losses_fullres_inputs(13, B, H, W)
+    inputs = {}
+    for (f, s), v in colors.items():
+        inputs[("color", f, s)] = inputs[("color_aug", f, s)] = torch.from_numpy(v)
+    for s in range(4):
+        inputs[("K", s)], inputs[("inv_K", s)] = kitti_K(H // 2 ** s, W // 2 ** s, B)
+    g = torch.Generator().manual_seed(521)
+    t = _make_trainer(L, Trainer, B, H, W)
+    disps = {s: torch.from_numpy(disps_np[s]).requires_grad_(True) for s in range(4)}
+    aa = {f: (torch.randn(B, 1, 3, generator=g) * 0.01).requires_grad_(True) for f in (-1, 1)}
+    tr = {f: (torch.randn(B, 1, 3, generator=g) * 0.05).requires_grad_(True) for f in (-1, 1)}
+    outputs = {("disp", s): disps[s] for s in range(4)}
+    for f in (-1, 1):
+        outputs[("cam_T_cam", 0, f)] = L.transformation_from_parameters(aa[f], tr[f], invert=(f < 0))
+    t.generate_images_pred(inputs, outputs)
+    torch.manual_seed(778)
+    losses = t.compute_losses(inputs, outputs)
+    losses["loss"].backward()
+    lat = lambda x: x[..., ::8, ::16]
+    d = dict(noise_seed=778, loss=losses["loss"], mono_reproj_lattice=lat(outputs["mono_reproj_loss"]),
+             mono_reproj_sum=outputs["mono_reproj_loss"].double().sum())
+    for s in range(4):
+        d["K_%d" % s], d["inv_K_%d" % s] = inputs[("K", s)], inputs[("inv_K", s)]
+        d["loss_%d" % s], d["smooth_%d" % s] = losses["loss/%d" % s], losses["mono_smooth_loss/%d" % s]
+        d["d_disp_rowsum_%d" % s] = disps[s].grad.double().sum(-1)
+        d["d_disp_abs_rowsum_%d" % s] = disps[s].grad.double().abs().sum(-1)
+        d["d_disp_lattice_%d" % s] = disps[s].grad[..., ::4, ::8]
+        d["depth_lattice_%d" % s] = lat(outputs[("depth", 0, s)])
+    for f in (-1, 1):
+        n = "m1" if f < 0 else "p1"
+        d["axisangle_" + n], d["translation_" + n] = aa[f], tr[f]
+        d["d_axisangle_" + n], d["d_translation_" + n] = aa[f].grad, tr[f].grad
+        d["T_" + n] = outputs[("cam_T_cam", 0, f)]
+        for s in (0, 3):
+            d["sample_lattice_%s_%d" % (n, s)] = outputs[("sample", f, s)][:, ::8, ::16]
+            d["color_lattice_%s_%d" % (n, s)] = lat(outputs[("color", f, s)])
+    save("losses_mono_fullres", d)
+
+
 def gen_smooth(L):
     g = torch.Generator().manual_seed(601)
     B, H, W = 2, 12, 20
@@ -536,6 +583,7 @@ def main():
     gen_warp_fullres(L)
     gen_ssim(L, Trainer)
     gen_losses(L, Trainer)
+    gen_losses_fullres(L, Trainer)
     gen_smooth(L)
     gen_postvol(L)
 
