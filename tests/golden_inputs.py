@@ -75,3 +75,13 @@ def losses_fullres_inputs(seed=13, B=2, H=192, W=640):
             colors[(f, s)] = np.ascontiguousarray(base.reshape(B, 3, H // k, k, W // k, k).mean((3, 5)), dtype=np.float32)
     disps = {s: (0.004 + 0.1 * bilinear_field(rng, (B, 1, H // 2 ** s, W // 2 ** s), 8).astype(np.float64)).astype(np.float32) for s in range(4)}
     return colors, disps
+
+
+def mvs_fullres_inputs(seed=14, B=2, H=192, W=640):
+    """MVS depth, mono depth and trust mask of the full-resolution MVS / fused-depth loss fixture (tests/golden/losses_mvs_fullres.npz;
+    the images are those of losses_fullres_inputs)"""
+    rng = np.random.default_rng(seed)
+    depth_mvs = bilinear_field(rng, (B, H, W), 8, 2.0, 22.0)
+    mono_depth = bilinear_field(rng, (B, 1, H, W), 8, 2.0, 22.0)
+    trust = bilinear_field(rng, (B, 1, H, W), 8)
+    return depth_mvs, mono_depth, trust

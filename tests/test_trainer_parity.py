@@ -190,6 +190,41 @@ def test_mvs_and_fuse_losses_match_reference(tag, flags, fused):
     assert_close_knife_edge(host(trust.grad), g["d_trust"], rtol=1e-4, max_outlier_frac=2e-3, what="d_trust")
 
 
+@pytest.mark.parametrize("fused", [1, 0])
+def test_mvs_and_fuse_losses_fullres_match_reference(fused):
+    """the MVS and fused-depth branches (auto-mask and MVS smoothness on) at 192 x 640 against the reference Trainer's own
+    compute_fuse_losses / generate_images_pred(is_mvs) / compute_losses(is_mvs) + backward (tests/golden/losses_mvs_fullres.npz)"""
+    from golden_inputs import losses_fullres_inputs, mvs_fullres_inputs
+    g = load_golden("losses_mvs_fullres")
+    colors, _ = losses_fullres_inputs()
+    dm, md, tm = mvs_fullres_inputs()
+    t = make_trainer(fused_photometric=fused, height=192, width=640, mask_mvs_auto=True, mvs_smooth_loss=True)
+    inputs = {("color", f, s): dev(v) for (f, s), v in colors.items()}
+    inputs[("K", 0)], inputs[("inv_K", 0)] = dev(g["K_0"]), dev(g["inv_K_0"])
+    depth_mvs, trust, mono_depth = dev(dm, True), dev(tm, True), dev(md)
+    outputs = {"depth_mvs": depth_mvs, ("cam_T_cam", 0, -1): dev(g["T_m1"]), ("cam_T_cam", 0, 1): dev(g["T_p1"])}
+    outputs["fused_depth"] = (1 - trust) * depth_mvs[:, None].detach() + trust * mono_depth
+    torch.manual_seed(int(g["noise_seed"]))
+    fuse_losses = t.compute_fuse_losses(inputs, outputs)
+    t.generate_images_pred(inputs, outputs, is_mvs=True)
+    mvs_losses = t.compute_losses(inputs, outputs, is_mvs=True)
+    for got, key in ((fuse_losses["loss"], "fuse_loss"), (mvs_losses["loss"], "mvs_loss"), (outputs["mvs_reproj_loss"], "mvs_reproj_loss"),
+                     (mvs_losses["mvs_smooth_loss/0"], "mvs_smooth_loss"), (fuse_losses["fuse_reproj_loss"], "fuse_reproj_loss")):
+        assert abs(float(got) - float(g[key])) < 1e-4 * abs(float(g[key])), (key, float(got), float(g[key]))
+    lat = lambda x: x[..., ::8, ::16]
+    # T is given here: warped frames bit-equal to the reference's
+    assert np.array_equal(lat(host(outputs[("mvs_color", -1)])), g["mvs_color_lattice_m1"])
+    assert np.array_equal(lat(host(outputs[("mvs_color_fuse", 1)])), g["mvs_color_fuse_lattice_p1"])
+    assert int(host(outputs[("mvs_mask", -1)]).astype(bool).sum()) == int(g["mvs_mask_count_m1"])
+    assert_close(lat(host(outputs["mvs_reprojection_loss"])), g["mvs_reprojection_lattice"])
+    (mvs_losses["loss"] + fuse_losses["loss"]).backward()
+    for tn, name in ((depth_mvs, "d_depth_mvs"), (trust, "d_trust")):
+        dd = host(tn.grad)
+        err = np.abs(dd.astype(np.float64).sum(-1) - g[name + "_rowsum"])
+        assert float(err.max()) <= 1e-4 * float(g[name + "_abs_rowsum"].max()), (name, float(err.max()))
+        assert_close_knife_edge(dd[..., ::4, ::8], g[name + "_lattice"], rtol=2e-4, what=name + " lattice")
+
+
 def test_process_batch_runs_and_has_reference_keys():
     """End-to-end step at BASELINE config 1 shape (64x128, D=16, B=1): output / loss keys of the reference
      are present, the loss is finite and every parameter receives a finite gradient."""

@@ -474,6 +474,31 @@ def gen_losses_fullres(L, Trainer):
             d["color_lattice_%s_%d" % (n, s)] = lat(outputs[("color", f, s)])
     save("losses_mono_fullres", d)
 
+    # ---- MVS + fused-depth branches at the same size (trainer.py:495-508, 621-673, 569-612), masks and MVS smoothness on
+    from golden_inputs import mvs_fullres_inputs
+    t3 = _make_trainer(L, Trainer, B, H, W, mask_mvs_auto=True, mvs_smooth_loss=True)
+    dm, md, tm = mvs_fullres_inputs(14, B, H, W)
+    depth_mvs, mono_depth, trust = torch.from_numpy(dm).requires_grad_(True), torch.from_numpy(md), torch.from_numpy(tm).requires_grad_(True)
+    out3 = {"depth_mvs": depth_mvs}
+    for f in (-1, 1):
+        out3[("cam_T_cam", 0, f)] = outputs[("cam_T_cam", 0, f)].detach()
+    out3["fused_depth"] = (1 - trust) * depth_mvs[:, None].detach() + trust * mono_depth  # trainer.py:413
+    torch.manual_seed(779)
+    fuse_losses = t3.compute_fuse_losses(inputs, out3)
+    t3.generate_images_pred(inputs, out3, is_mvs=True)
+    mvs_losses = t3.compute_losses(inputs, out3, is_mvs=True)
+    (mvs_losses["loss"] + fuse_losses["loss"]).backward()
+    rs = lambda x: x.double().sum(-1)
+    save("losses_mvs_fullres", dict(noise_seed=779, T_m1=out3[("cam_T_cam", 0, -1)], T_p1=out3[("cam_T_cam", 0, 1)],
+                                    K_0=inputs[("K", 0)], inv_K_0=inputs[("inv_K", 0)],
+                                    mvs_loss=mvs_losses["loss"], fuse_loss=fuse_losses["loss"], fuse_reproj_loss=fuse_losses["fuse_reproj_loss"],
+                                    mvs_reproj_loss=out3["mvs_reproj_loss"], mvs_smooth_loss=mvs_losses["mvs_smooth_loss/0"],
+                                    mvs_reprojection_lattice=lat(out3["mvs_reprojection_loss"]), mvs_color_lattice_m1=lat(out3[("mvs_color", -1)]),
+                                    mvs_color_fuse_lattice_p1=lat(out3[("mvs_color_fuse", 1)]), mvs_mask_count_m1=out3[("mvs_mask", -1)].sum(),
+                                    d_depth_mvs_rowsum=rs(depth_mvs.grad), d_depth_mvs_abs_rowsum=rs(depth_mvs.grad.abs()),
+                                    d_depth_mvs_lattice=depth_mvs.grad[..., ::4, ::8],
+                                    d_trust_rowsum=rs(trust.grad), d_trust_abs_rowsum=rs(trust.grad.abs()), d_trust_lattice=trust.grad[..., ::4, ::8]))
+
 
 def gen_smooth(L):
     g = torch.Generator().manual_seed(601)
