@@ -62,10 +62,16 @@ def make(group=None):
         fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
         d = DirectAllReduce(g, comm, fn)
         # the first direct call, checked: sum of ones = number of ranks, on every rank, or nobody uses the path
-        check = torch.ones(4, device=dev, dtype=torch.float64)
-        d(check)
-        torch.cuda.synchronize()
-        ok = torch.tensor([1.0 if bool((check == float(d.size)).all()) else 0.0], device=dev)
+        # (in the two element types the BatchNorm layers use, with rank-dependent addends: 1 + rank summed over the ranks)
+        rank = dist.get_rank(g)
+        want = float(d.size * (d.size + 1) // 2)
+        good = True
+        for dt in (torch.float64, torch.float32):
+            check = torch.full((6,), float(rank + 1), device=dev, dtype=dt)
+            d(check)
+            torch.cuda.synchronize()
+            good = good and bool((check == want).all())
+        ok = torch.tensor([1.0 if good else 0.0], device=dev)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=g)
         d.calls = 0
         return d if float(ok.item()) == 1.0 else None
