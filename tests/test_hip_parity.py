@@ -1154,7 +1154,11 @@ def test_reg3d_fused_bn_paths_agree(ops):
 @pytest.mark.parametrize("fused,layout,feat", [(False, "bgd", "nchw"), (True, "bgd", "nchw"), (True, "ndhwc", "nchw"), (True, "ndhwc", "nhwc")])
 @pytest.mark.parametrize("case", [dict(B=2, C=32, G=16, h=24, w=40, D=12), dict(B=1, C=32, G=16, h=48, w=160, D=16),
                                   dict(B=1, C=32, G=16, h=24, w=40, D=13),   # odd slice: the unpaired tail of the 16-byte store path
-                                  dict(B=1, C=16, G=8, h=24, w=40, D=11)])   # two lanes per pixel
+                                  dict(B=1, C=16, G=8, h=24, w=40, D=11),   # two lanes per pixel
+                                  # wild poses (an untrained pose network): with channels-last features the 2-byte kernels walk these
+                                  # sub-slices in gather mode (16-byte loads from L2 forward, float atomics backward)
+                                  dict(B=2, C=32, G=16, h=32, w=96, D=16, rot=0.3, trans=2.0),
+                                  dict(B=2, C=64, G=16, h=32, w=96, D=16, rot=0.1, trans=1.0)])
 def test_costvol_half_io_vs_oracle(ops, oracle_lib, case, fused, layout, feat, dtype, tol_rounded, tol_exact):
     """BASELINE configs 4 / 5 precision: bf16 or fp16 feature maps and volume, fp32 arithmetic in between.  The oracle gets
     the *rounded* features as floats; the kernel's output must equal the oracle's fp32 volume rounded to the format (a
@@ -1167,7 +1171,7 @@ def test_costvol_half_io_vs_oracle(ops, oracle_lib, case, fused, layout, feat, d
     ref, src = ref_t.float().numpy(), src_t.float().numpy()
     K, invK = kitti_K(h, w, B)
     prior = (2 + 20 * rng.random((B, 1, h, w))).astype(np.float32)
-    pose = rand_pose(oracle_lib, rng, B, 0.01, 0.05)
+    pose = rand_pose(oracle_lib, rng, B, case.get("rot", 0.01), case.get("trans", 0.05))
     hyp = oracle_lib.schedule_depth_range(prior, D, 0.3, None, "inverse")
     gout_t = torch.from_numpy(rng.standard_normal((B, D, G, h, w)).astype(np.float32)).to(dtype)
     exp = oracle_lib.costvol_grouped(ref, src, K, invK, hyp, pose, G)
