@@ -38,6 +38,12 @@ using namespace mdp;
 constexpr int MAXF = MD_PHOTO_MAX_FRAMES, MAXS = MD_PHOTO_MAX_SCALES;
 constexpr int FT_W = 32, FT_H = 16, FP_W = FT_W + 2, FP_H = FT_H + 2, FP_N = FP_W * FP_H;  // forward tile, + halo 1
 constexpr int BT_W = 32, BT_H = 8;                                                         // backward tile
+#ifndef MD_PHOTO_BWD_WAVES
+#define MD_PHOTO_BWD_WAVES 4     // waves per SIMD the backward is compiled for (up to two source frames): 128 registers, 9 spilled at F = 2; 3: 135, none (A/B: 201 -> 177 us)
+#endif
+#ifndef MD_PHOTO_BWD_ONEPASS
+#define MD_PHOTO_BWD_ONEPASS 1   // coefficient maps of all frames in one pass (photo_bwd_kernel); 0: one masked pass per frame (A/B)
+#endif
 constexpr int B2_W = BT_W + 4, B2_H = BT_H + 4, B2_N = B2_W * B2_H;                        // + halo 2 (images)
 constexpr int B1_W = BT_W + 2, B1_H = BT_H + 2, B1_N = B1_W * B1_H;                        // + halo 1 (coefficients)
 
@@ -314,13 +320,14 @@ __global__ __launch_bounds__(256) void photo_fwd_finish_kernel(const float *__re
 // ------------------------------------------------------------------------------------------------ backward
 // three waves per SIMD (<= 168 registers) for up to two source frames, two beyond
 template <int F>
-__global__ __launch_bounds__(256, (F <= 2 ? 3 : 2)) void photo_bwd_kernel(const md_photo_desc a, float *__restrict__ gup, float *__restrict__ wsP) {
+__global__ __launch_bounds__(256, (F <= 2 ? MD_PHOTO_BWD_WAVES : 2)) void photo_bwd_kernel(const md_photo_desc a, float *__restrict__ gup, float *__restrict__ wsP) {
     extern __shared__ float4 lds[];
     float4 *tg = lds;                         // target, halo 2
     float4 *wp = lds + B2_N;                  // wp[f * B2_N + i]: warped frame f, halo 2
     float4 *cf = lds + (1 + F) * B2_N;        // cf[k * B1_N + i], k = 0..2: coefficient maps A, B, C of the current frame
     __shared__ float redf[16 * 12];
     __shared__ float camS[MAXF * 12 + 9];
+    __shared__ signed char csel[B1_N];        // frame whose coefficients a halo-1 position holds (-1: none)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int H = a.H, W = a.W;
     const int tiles_x = (W + BT_W - 1) / BT_W, nblk = tiles_x * ((H + BT_H - 1) / BT_H);
@@ -400,10 +407,68 @@ __global__ __launch_bounds__(256, (F <= 2 ? 3 : 2)) void photo_bwd_kernel(const 
             for (int f = 0; f < F; ++f) reinterpret_cast<v4f *>(wp)[f * B2_N + i] = st[k][1 + f];
         }
     }
+    // Coefficient maps A, B, C at halo 1 (d SSIM term / d mu_x, E[x^2], E[xy] of the window centred there, times the upstream
+    // factor), non-zero only where a frame is the selected minimum and the mask is set.  ONE pass for all frames
+    // (MD_PHOTO_BWD_ONEPASS): every position belongs to at most one frame -- the arg-min -- so a lane takes ITS frame's window
+    // from LDS (wp + frame * B2_N) and the moments are computed once per position.  As first written the phase ran once per
+    // frame with the positions of the other frames masked off: with a selection that varies from pixel to pixel (every step of a
+    // run from random weights; profiles/r04_bench_line.json) both passes executed in nearly every wave, twice the phase's 27 taps
+    // x 5 moments x 3 channels per position for the same results.  only_f >= 0: the per-frame form (A/B builds).
+    auto coeff_phase = [&](int only_f) {
+#pragma unroll
+        for (int k = 0; k < NCF; ++k) {
+            const int i = tid + 256 * k;
+            if (i >= B1_N) break;
+            const int cy = i / B1_W, cx = i % B1_W;
+            float4 A = make_float4(0.f, 0.f, 0.f, 0.f), Bc = A, Cc = A;
+            const int fs = selc[k] & 0x7f;
+            const bool on = (selc[k] & 0x80) && fs < F && (only_f < 0 || fs == only_f);
+            if (on) {
+                const float4 *wf = wp + fs * B2_N;
+                const float gs = gscale * mskc[k] * a.ssim_w / 3.f;
+                float cA[3], cB[3], cC[3];
+                {
+                    // each tap's float4 is read from LDS once for its three channels (read per channel, the kernel issued 400
+                    // DS instructions per wave and was LDS-bound: SQ_LDS_IDX_ACTIVE 60 % of its duration); sums in the
+                    // reference's order, no contraction (see the forward)
+#pragma clang fp contract(off)
+                    Moments m[3];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) m[c] = Moments{0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                        for (int dx = 0; dx < 3; ++dx) {
+                            const float4 x4 = wf[(cy + dy) * B2_W + cx + dx], y4 = tg[(cy + dy) * B2_W + cx + dx];
+#pragma unroll
+                            for (int c = 0; c < 3; ++c) {
+                                const float xv = f4c(x4, c), yv = f4c(y4, c);
+                                m[c].mux += xv; m[c].muy += yv; m[c].ex2 += xv * xv; m[c].ey2 += yv * yv; m[c].exy += xv * yv;
+                            }
+                        }
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        m[c].mux = div9(m[c].mux); m[c].muy = div9(m[c].muy); m[c].ex2 = div9(m[c].ex2);
+                        m[c].ey2 = div9(m[c].ey2); m[c].exy = div9(m[c].exy);
+                        ssim_coeffs(m[c], gs, cA[c], cB[c], cC[c]);
+                    }
+                }
+                A = make_float4(cA[0], cA[1], cA[2], 0.f);
+                Bc = make_float4(cB[0], cB[1], cB[2], 0.f);
+                Cc = make_float4(cC[0], cC[1], cC[2], 0.f);
+            }
+            cf[i] = A; cf[B1_N + i] = Bc; cf[2 * B1_N + i] = Cc;
+            csel[i] = on ? (signed char)fs : (signed char)-1;
+        }
+    };
     float r0, r1, r2;
     md_ray(cam[0], (float)qx, (float)qy, r0, r1, r2);
     float d_depth = 0.f;
     __syncthreads();
+    if (use_ssim && MD_PHOTO_BWD_ONEPASS) {
+        coeff_phase(-1);
+        __syncthreads();
+    }
 
 #pragma unroll
     for (int f = 0; f < F; ++f) {
@@ -426,48 +491,8 @@ __global__ __launch_bounds__(256, (F <= 2 ? 3 : 2)) void photo_bwd_kernel(const 
             __builtin_amdgcn_sched_barrier(0);   // keep the loads up here: the scheduler otherwise sinks them to their first use
         }
         // ---- coefficient maps at halo 1, only where frame f is the selected minimum and the mask is set
-        if (use_ssim) {
-#pragma unroll
-            for (int k = 0; k < NCF; ++k) {
-                const int i = tid + 256 * k;
-                if (i >= B1_N) break;
-                const int cy = i / B1_W, cx = i % B1_W;
-                float4 A = make_float4(0.f, 0.f, 0.f, 0.f), Bc = A, Cc = A;
-                if (selc[k] == (unsigned char)(0x80 | f)) {
-                    const float gs = gscale * mskc[k] * a.ssim_w / 3.f;
-                    float cA[3], cB[3], cC[3];
-                    {
-                        // each tap's float4 is read from LDS once for its three channels (read per channel, the kernel issued 400
-                        // DS instructions per wave and was LDS-bound: SQ_LDS_IDX_ACTIVE 60 % of its duration); sums in the
-                        // reference's order, no contraction (see the forward)
-#pragma clang fp contract(off)
-                        Moments m[3];
-#pragma unroll
-                        for (int c = 0; c < 3; ++c) m[c] = Moments{0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                        for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-                            for (int dx = 0; dx < 3; ++dx) {
-                                const float4 x4 = wf[(cy + dy) * B2_W + cx + dx], y4 = tg[(cy + dy) * B2_W + cx + dx];
-#pragma unroll
-                                for (int c = 0; c < 3; ++c) {
-                                    const float xv = f4c(x4, c), yv = f4c(y4, c);
-                                    m[c].mux += xv; m[c].muy += yv; m[c].ex2 += xv * xv; m[c].ey2 += yv * yv; m[c].exy += xv * yv;
-                                }
-                            }
-#pragma unroll
-                        for (int c = 0; c < 3; ++c) {
-                            m[c].mux = div9(m[c].mux); m[c].muy = div9(m[c].muy); m[c].ex2 = div9(m[c].ex2);
-                            m[c].ey2 = div9(m[c].ey2); m[c].exy = div9(m[c].exy);
-                            ssim_coeffs(m[c], gs, cA[c], cB[c], cC[c]);
-                        }
-                    }
-                    A = make_float4(cA[0], cA[1], cA[2], 0.f);
-                    Bc = make_float4(cB[0], cB[1], cB[2], 0.f);
-                    Cc = make_float4(cC[0], cC[1], cC[2], 0.f);
-                }
-                cf[i] = A; cf[B1_N + i] = Bc; cf[2 * B1_N + i] = Cc;
-            }
+        if (use_ssim && !MD_PHOTO_BWD_ONEPASS) {
+            coeff_phase(f);
             __syncthreads();
         }
         float dP[12];
@@ -490,7 +515,9 @@ __global__ __launch_bounds__(256, (F <= 2 ? 3 : 2)) void photo_bwd_kernel(const 
                         const float wx = 1.f + ((qx == 1 && px == 0) ? 1.f : 0.f) + ((qx == W - 2 && px == W - 1) ? 1.f : 0.f);
                         const int o = (ty + 1 + dy) * B1_W + tx + 1 + dx;
                         const float4 A = cf[o], Bc = cf[B1_N + o], Cc = cf[2 * B1_N + o];
-                        const float wgt = wy * wx;
+                        // (one-pass maps hold every frame's coefficients: those of the other frames contribute exact zeros, as the
+                        // zero-filled per-frame maps did)
+                        const float wgt = (!MD_PHOTO_BWD_ONEPASS || csel[o] == (signed char)f) ? wy * wx : 0.f;
 #pragma unroll
                         for (int c = 0; c < 3; ++c) { gA[c] += wgt * f4c(A, c); gB[c] += wgt * f4c(Bc, c); gC[c] += wgt * f4c(Cc, c); }
                     }
