@@ -148,3 +148,31 @@ def test_gradsync_packs_buckets_and_zeroes_unused_parameters():
         # d/dW of sum(W x + b) = x summed over the 3 rows, mean over ranks: 3 * mean(rank + 1 + step) = 3 * (1.5 + step); d/db = 3
         assert np.allclose(ga[step][0], 3.0 * (1.5 + step)) and np.allclose(ga[step][1], 3.0)
         assert not ga[step][2].any() and not ga[step][3].any()
+
+
+def test_direct_rccl_path_declines_without_an_nccl_group():
+    """movedepth_amd/rccl_direct.py: no process group, or a group on another backend (the gloo runs of this suite), -> None and the
+    callers keep torch.distributed.all_reduce; ops._group_all_reduce / _group_size dispatch on what they are given"""
+    sys.path.insert(0, ROOT)
+    from movedepth_amd import rccl_direct
+
+    assert not dist.is_initialized() and rccl_direct.make(None) is None
+    port = _free_port()
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        assert rccl_direct.make(None) is None
+        from movedepth_amd import ops
+        t = torch.ones(3)
+        ops._group_all_reduce(t, dist.group.WORLD)
+        assert ops._group_size(dist.group.WORLD) == 1 and torch.equal(t, torch.ones(3))
+
+        class Fake:                      # what a DirectAllReduce looks like to the callers
+            size, seen = 4, []
+            def __call__(self, x):
+                self.seen.append(x)
+        f = Fake()
+        ops._group_all_reduce(t, f)
+        assert ops._group_size(f) == 4 and f.seen and f.seen[0] is t
+    finally:
+        dist.destroy_process_group()
