@@ -85,3 +85,17 @@ def mvs_fullres_inputs(seed=14, B=2, H=192, W=640):
     mono_depth = bilinear_field(rng, (B, 1, H, W), 8, 2.0, 22.0)
     trust = bilinear_field(rng, (B, 1, H, W), 8)
     return depth_mvs, mono_depth, trust
+
+
+def postvol_launch_inputs(seed=15, B=6, D=96, h=48, w=160):
+    """logits of the regulariser, depth prior, and the convex up-sampling's inputs at BASELINE config 2's launch shape
+    (tests/golden/postvol_launch.npz holds the reference's small outputs).  numpy's own generators and float64 -> float32 casts only."""
+    rng = np.random.default_rng(seed)
+    logits = (rng.standard_normal((B, D, h, w)) * 2).astype(np.float32)
+    prior = bilinear_field(rng, (B, 1, h, w), 8, 2.0, 22.0)
+    g_depth = rng.standard_normal((B, h, w)).astype(np.float32)
+    g_ent = rng.standard_normal((B, 1, h, w)).astype(np.float32)
+    up_depth = bilinear_field(rng, (B, h, w), 8, 2.0, 22.0)
+    up_mask = rng.standard_normal((B, 16 * 9, h, w)).astype(np.float32)
+    g_up = rng.standard_normal((B, 4 * h, 4 * w)).astype(np.float32)
+    return logits, prior, g_depth, g_ent, up_depth, up_mask, g_up

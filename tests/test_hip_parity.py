@@ -678,6 +678,39 @@ def test_postvol_vs_oracle_and_torch(ops, oracle_lib, shape, radius):
     assert_close(host(lg.grad), host(lt.grad), rtol=2e-4, what="d_logits")
 
 
+def test_postvol_launch_shape_reference_fixture(ops):
+    """softmax -> entropy / localmax and the convex up-sampling, forward and backward, at BASELINE config 2's launch shape (B=6, D=96,
+    48x160 -> 192x640) against the REFERENCE's own functions (tests/golden/postvol_launch.npz, tools/gen_golden.py gen_postvol_launch;
+    inputs rebuilt from a seed): row / plane sums within 1e-4 of the absolute sums, lattices within 1e-5 / 2e-4."""
+    from golden_inputs import postvol_launch_inputs
+    g = load_golden("postvol_launch")
+    logits, prior, g_depth, g_ent, up_depth, up_mask, g_up = postvol_launch_inputs()
+    hyp = host(ops.schedule_depth_range(dev(prior), 96, 0.3, None, "inverse"))
+    lat = lambda x: x[..., ::8, ::16]
+    assert_close(lat(1 / hyp[:, -1]), g["inv_hi_lattice"], rtol=1e-6)
+    lg = dev(logits, True)
+    depth, ent, _ = ops.softmax_entropy_localmax(lg, dev(1 / hyp[:, -1]), dev(1 / hyp[:, 0]), 1)
+    rs = lambda x: x.astype(np.float64).sum(-1)
+    assert_close(lat(host(depth)), g["depth_lattice"], rtol=1e-5, what="depth")
+    assert_close(lat(host(ent)), g["entropy_lattice"], rtol=1e-5, what="entropy")
+    assert np.abs(rs(host(depth)) - g["depth_rowsum"]).max() <= 1e-5 * np.abs(g["depth_rowsum"]).max()
+    assert np.abs(rs(host(ent)) - g["entropy_rowsum"]).max() <= 1e-5 * np.abs(g["entropy_rowsum"]).max()
+    ((depth * dev(g_depth)).sum() + (ent * dev(g_ent)).sum()).backward()
+    dl = host(lg.grad)
+    assert np.abs(dl.astype(np.float64).sum((-1, -2)) - g["d_logits_planesum"]).max() <= 1e-4 * g["d_logits_abs_planesum"].max()
+    assert_close(lat(dl)[:, ::8], g["d_logits_lattice"], rtol=2e-4, what="d_logits")
+    ud, um = dev(up_depth, True), dev(up_mask, True)
+    up = ops.convex_upsample(ud, um, 2)
+    assert_close(host(up)[..., ::16, ::32], g["up_lattice"], rtol=1e-5, what="up-sampled depth")
+    assert np.abs(rs(host(up)) - g["up_rowsum"]).max() <= 1e-5 * np.abs(g["up_rowsum"]).max()
+    (up * dev(g_up)).sum().backward()
+    gd, gm = host(ud.grad), host(um.grad)
+    assert np.abs(rs(gd) - g["d_up_depth_rowsum"]).max() <= 1e-4 * g["d_up_depth_abs_rowsum"].max()
+    assert_close(lat(gd), g["d_up_depth_lattice"], rtol=2e-5, what="d_up_depth")
+    assert np.abs(rs(gm)[:, ::9] - g["d_up_mask_rowsum"]).max() <= 1e-4 * g["d_up_mask_abs_rowsum"].max()
+    assert_close(lat(gm)[:, ::12], g["d_up_mask_lattice"], rtol=2e-5, what="d_up_mask")
+
+
 def test_convex_upsample_golden(ops):
     g = load_golden("postvol")
     depth, mask = dev(g["up_depth"], True), dev(g["up_mask"], True)

@@ -545,6 +545,35 @@ def gen_postvol(L):
                          d_up_mask=mask.grad))
 
 
+def gen_postvol_launch(L):
+    """softmax -> entropy / localmax (trainer.py:366-371) and convex_upsample (layers.py:200-214) with autograd at BASELINE config 2's
+    launch shape (B=6, D=96, 48x160 -> 192x640), from the reference's own functions; inputs rebuilt from a seed
+    (tests/golden_inputs.py), the fixture keeps row sums / absolute row sums and lattices."""
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tests"))
+    from golden_inputs import postvol_launch_inputs
+    B, D, h, w = 6, 96, 48, 160
+    logits, prior, g_depth, g_ent, up_depth, up_mask, g_up = (torch.from_numpy(a) for a in postvol_launch_inputs(15, B, D, h, w))
+    logits.requires_grad_(True)
+    prob = F.softmax(logits, 1)
+    hyp = L.schedule_depth_rangev2(prior, D, 0.3)
+    ent = L.entropy(prob, dim=1, keepdim=True)
+    dm = L.localmax(prob, 1, D, 1 / hyp[:, -1], 1 / hyp[:, 0])
+    ((dm * g_depth).sum() + (ent * g_ent).sum()).backward()
+    up_depth.requires_grad_(True)
+    up_mask.requires_grad_(True)
+    up = L.convex_upsample(up_depth, up_mask, 2)
+    (up * g_up).sum().backward()
+    rs = lambda x: x.double().sum(-1)
+    lat = lambda x: x[..., ::8, ::16]
+    save("postvol_launch", dict(inv_hi_lattice=lat(1 / hyp[:, -1]), inv_lo_lattice=lat(1 / hyp[:, 0]),
+                                depth_rowsum=rs(dm), depth_lattice=lat(dm), entropy_rowsum=rs(ent), entropy_lattice=lat(ent),
+                                d_logits_planesum=logits.grad.double().sum((-1, -2)), d_logits_abs_planesum=logits.grad.double().abs().sum((-1, -2)), d_logits_lattice=lat(logits.grad)[:, ::8],
+                                up_rowsum=rs(up), up_lattice=up[..., ::16, ::32],
+                                d_up_depth_rowsum=rs(up_depth.grad), d_up_depth_abs_rowsum=rs(up_depth.grad.abs()), d_up_depth_lattice=lat(up_depth.grad),
+                                d_up_mask_rowsum=rs(up_mask.grad)[:, ::9], d_up_mask_abs_rowsum=rs(up_mask.grad.abs())[:, ::9],
+                                d_up_mask_lattice=lat(up_mask.grad)[:, ::12]))
+
+
 def gen_prob_conv(networks):
     """reg3d's last layer through the reference's own module (networks/resnet_encoder.py:254, applied :277):
     prob(x).squeeze(1) on the tensor the U-Net hands it, with gradients to that tensor and to the weight.
@@ -611,6 +640,7 @@ def main():
     gen_losses_fullres(L, Trainer)
     gen_smooth(L)
     gen_postvol(L)
+    gen_postvol_launch(L)
 
 
 if __name__ == "__main__":
