@@ -1,13 +1,14 @@
 """The trainer's `--ddp --sync_bn 1` path on the backend the multi-GPU runs use: torch.distributed "nccl" (= RCCL on ROCm), here
-with a group of ONE rank -- all a one-GPU box can host.  Every collective of a step (the constructor's weight broadcast, the
-gradient buckets' all-reduces launched from autograd hooks, the 2C-double / 2C-float all-reduces of every synchronised BatchNorm
-call, forward and backward) goes through RCCL -- the gradient buckets on torch's communicator stream, ordered against the kernels by
-ProcessGroupNCCL's stream events, the BatchNorm sums by direct ncclAllReduce calls on the compute stream (rccl_direct.py); the gloo tests (tests/test_dp_syncbn_gpu.py) cannot see a mistake there: gloo collectives on GPU
-tensors are synchronous host copies.  A group of one makes every reduction the identity, so the step must reproduce the
-non-distributed step with the same normalisation kernels (--force_sync_bn 1): loss, gradients, BatchNorm running statistics.  Not
-bit for bit -- the plane sweep's d_src sums are float atomics between neighbouring tiles, and the step amplifies a 1e-7 difference
-to 1e-3 in some sub-networks (tools/diag/step_sensitivity.py) -- so the bounds are those of tests/test_dp_syncbn_gpu.py; a
-collective reading its buffer before the kernel in front of it has written it misses them by orders of magnitude.
+with a group of ONE rank -- all a one-GPU box can host.  Every collective of a step goes through RCCL: the constructor's weight
+broadcast and the gradient buckets' all-reduces (launched from autograd hooks) on torch's communicator stream, ordered against the
+kernels by ProcessGroupNCCL's stream events; the 2C-double / 2C-float sums of every synchronised BatchNorm call, forward and
+backward, as direct ncclAllReduce calls on the compute stream (movedepth_amd/rccl_direct.py).  The gloo tests
+(tests/test_dp_syncbn_gpu.py) cannot see a mistake there: gloo collectives on GPU tensors are synchronous host copies.
+A group of one makes every reduction the identity, so the step must reproduce the non-distributed step with the same normalisation
+kernels (--force_sync_bn 1): loss, gradients, BatchNorm running statistics.  Not bit for bit -- the plane sweep's d_src sums are
+float atomics between neighbouring tiles, and the step amplifies a 1e-7 difference to 1e-3 in some sub-networks
+(tools/diag/step_sensitivity.py) -- so the bounds are those of tests/test_dp_syncbn_gpu.py; a collective reading its buffer before
+the kernel in front of it has written it misses them by orders of magnitude.
 Reference: trainer.py:49, 69-135."""
 import os
 import socket
