@@ -216,6 +216,25 @@ def gpu_hot_path_ms_per_image(opt, device, iters=20):
                                                     for k, v in per_entry.items()}
 
 
+def start_watchdog(seconds):
+    """A hang must become a non-zero exit code.  torch's own watchdog covers collectives issued through torch.distributed (the
+    process group is created with a timeout, trainer.py); it does not see a rank that stalls elsewhere, nor ncclAllReduce calls
+    made directly (rccl_direct, opt-in).  A daemon thread ends the PROCESS -- os._exit, no clean-up that could block on the same
+    hang -- so that torch.distributed.run tears the other ranks down and the launcher returns rc != 0."""
+    if seconds <= 0:
+        return None
+    import threading
+
+    def fire():
+        sys.stderr.write("bench.py: watchdog: not finished after %.0f s (rank %s) -- aborting with exit code 124\n" % (seconds, os.environ.get("RANK", "0")))
+        sys.stderr.flush()
+        os._exit(124)
+    t = threading.Timer(seconds, fire)
+    t.daemon = True
+    t.start()
+    return t
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -225,7 +244,11 @@ def main():
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--trainer_args", default="", help="extra movedepth_amd options, e.g. '--hip_prob_conv 0' for an A/B")
     ap.add_argument("--epoch", type=int, default=0, help="trainer.epoch during the run (> ztrans_start_epc: velocity-guided bins)")
+    ap.add_argument("--watchdog_s", type=float, default=float(os.environ.get("MD_BENCH_WATCHDOG_S", "0")),
+                    help="abort with exit code 124 when the run has not finished after this many seconds (default: 1800 for --gpus > 1, "
+                         "where a rank that died or a collective that cannot complete leaves the others waiting; off for one GPU)")
     a = ap.parse_args()
+    start_watchdog(a.watchdog_s if a.watchdog_s > 0 else (1800.0 if (a.gpus > 1 or int(os.environ.get("WORLD_SIZE", "1")) > 1) else 0.0))
     # stdout carries exactly one JSON line.  The convolution libraries write diagnostics to file descriptor 1 from C++ (CK's
     # "GridwiseOp: Problemsize descriptor dimension check failure" under fp16 autocast): point fd 1 at stderr for the run and
     # keep the real stdout for the line.
@@ -377,7 +400,10 @@ def main():
                       "train-step images/sec at %dx%d, D=%d; cost-volume HBM GB/s vs roofline" % (opt.height, opt.width, opt.num_depth_bins),
             "value": gb * a.steps / elapsed, "unit": "images/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
-            "host_issue_ms_per_step": 1e3 * host_issue / a.steps,   # launching thread only: close to ms_per_step = the host is the limit
+            # wall time of the launching thread's loop WITHOUT the final synchronise.  Not evidence of a host limit: the HIP queue
+            # back-pressures, so in a GPU-bound step (this one: 43.4 ms of kernel time per step in the trace) the thread is
+            # held at the queue's depth and this equals ms_per_step too; it only says something when it is well BELOW ms_per_step
+            "host_issue_ms_per_step": 1e3 * host_issue / a.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": {"none": "f32", "bf16": "bf16", "fp16": "f16"}[opt.amp], "data": "synthetic",
             "config": {"workload": ("BASELINE config %d: " % (2 if world == 1 else 3) if not a.trainer_args else "") +
                                    "KITTI %dx%d, ResNet%d, D=%d, batch %d/GPU, %s, %d-frame cost volume%s, "

@@ -375,6 +375,10 @@ int md_kernel_timing_read(const char *name, double *avg_us, double *min_us, int 
  * [1] windows staged (sub-slices), [2] window-fit attempts, [3] (lane, sub-slice) pairs that had to redo steps from global memory, [4] wave-level
  * cell-change blocks executed (forward: coefficient rebuilds, backward: flushes), [5] lanes active in them, [6] wave-steps. */
 int md_costvol_stats(int enable, unsigned long long *out8);
+/* ... and, while they are on, the lifetime in shader cycles of every workgroup of the launches since the last clear (entry
+ * blockIdx.x, summed over launches; the first 8192 workgroups): copies min(cap, 8192) entries, returns that count (0: never enabled).
+ * Read it BEFORE md_costvol_stats(., out8), which clears.  max / mean over the non-zero entries = how evenly a launch's work is spread. */
+int md_costvol_stats_wg(unsigned long long *out, int cap);
 /* the individual durations, in launch order: fills us[0 .. min(n, cap)) and returns n (>= 0) */
 int md_kernel_timing_list(const char *name, double *us, int cap);
 

@@ -86,6 +86,7 @@ SIGNATURES = {
     "md_project3d": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp]),
     "md_kernel_timing_enable": (_i, [_i]),
     "md_costvol_stats": (_i, [_i, ctypes.POINTER(ctypes.c_ulonglong)]),
+    "md_costvol_stats_wg": (_i, [ctypes.POINTER(ctypes.c_ulonglong), _i]),
     "md_kernel_timing_list": (_i, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_double), _i]),
     "md_kernel_timing_read": (_i, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
                                    ctypes.POINTER(_i)]),

@@ -13,7 +13,7 @@ void md_set_error(const char *fmt, ...) {
 }
 
 extern "C" const char *md_last_error(void) { return g_err; }
-extern "C" int md_abi_version(void) { return 15; }
+extern "C" int md_abi_version(void) { return 16; }
 
 // ---------------------------------------------------------------- per-kernel timing (measurement only)
 #include <vector>
@@ -24,16 +24,26 @@ std::vector<TimingRec> g_recs;
 }  // namespace
 
 // Work counters of the channels-last plane-sweep kernels (diagnostics: how often windows are staged, taps miss them, cells
-// change).  8 x u64 in device memory, allocated on first enable.
+// change).  8 x u64 in device memory, allocated on first enable; behind them MD_STATS_WG_CAP more: the lifetime of every
+// workgroup of the launch in shader cycles (entry 8 + blockIdx.x), i.e. how evenly the launch's work was spread.
 namespace { unsigned long long *g_stats = nullptr; bool g_stats_on = false; }
+constexpr int MD_STATS_WG_CAP = 8192;
 unsigned long long *md_stats_buffer() { return g_stats_on ? g_stats : nullptr; }
+extern "C" int md_costvol_stats_wg(unsigned long long *out, int cap) {
+    MD_REQUIRE(out && cap > 0, "md_costvol_stats_wg: null argument");
+    if (!g_stats) return 0;
+    const int n = cap < MD_STATS_WG_CAP ? cap : MD_STATS_WG_CAP;
+    MD_CHECK_HIP(hipDeviceSynchronize());
+    MD_CHECK_HIP(hipMemcpy(out, g_stats + 8, n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return n;
+}
 extern "C" int md_costvol_stats(int enable, unsigned long long *out8) {
-    if (enable && !g_stats) MD_CHECK_HIP(hipMalloc(&g_stats, 8 * sizeof(unsigned long long)));
+    if (enable && !g_stats) MD_CHECK_HIP(hipMalloc(&g_stats, (8 + MD_STATS_WG_CAP) * sizeof(unsigned long long)));
     if (out8 && g_stats) {
         MD_CHECK_HIP(hipDeviceSynchronize());
         MD_CHECK_HIP(hipMemcpy(out8, g_stats, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     }
-    if (g_stats) MD_CHECK_HIP(hipMemset(g_stats, 0, 8 * sizeof(unsigned long long)));
+    if (g_stats) MD_CHECK_HIP(hipMemset(g_stats, 0, (8 + MD_STATS_WG_CAP) * sizeof(unsigned long long)));
     g_stats_on = enable != 0;
     return MD_OK;
 }

@@ -146,6 +146,16 @@ class KITTIRAWDataset(torch.utils.data.Dataset):
         return inputs
 
 
+def _seed_worker(_worker_id):
+    """worker_init_fn (module level: picklable under the spawn / forkserver start methods): DataLoader has seeded torch's generator
+    of this worker from the loader's base seed; carry it to python's and numpy's, which the augmentation draws from."""
+    import random
+
+    base = torch.initial_seed() % (2 ** 32)
+    random.seed(base)
+    np.random.seed(base)
+
+
 def make_loader(dataset, batch_size, rank=0, world_size=1, shuffle=True, num_workers=0, seed=0, drop_last=True):
     """DataLoader over `dataset` with the reference's sharding (one DistributedSampler-style rank-strided shard per process,
     trainer.py:171-179; drop_last as there).  Returns (loader, sampler-or-None): call sampler.set_epoch(e) per epoch."""
@@ -158,16 +168,13 @@ def make_loader(dataset, batch_size, rank=0, world_size=1, shuffle=True, num_wor
     # stream.  The loader's own generator -- from which DataLoader derives each worker's base seed -- therefore folds in the
     # rank and the dataset's seed, and worker_init_fn carries that base seed to python's and numpy's generators (torch's is
     # seeded by DataLoader itself).  With num_workers = 0 the draws are the main process's, seeded alike on every rank by train.py exactly as upstream (train.py:8-19).
-    gen = torch.Generator()
-    gen.manual_seed(int(seed) + 7919 * int(getattr(dataset, "seed", 0)) + 1000003 * int(rank))
-
-    def _seed_worker(_worker_id):
-        import random
-
-        base = torch.initial_seed() % (2 ** 32)
-        random.seed(base)
-        np.random.seed(base)
-
+    # One process without workers is the reference's own situation (train.py:8-19 seeds, trainer.py:172-179 builds the loader
+    # without a generator): the shuffle order then comes from the globally seeded torch generator, exactly as upstream -- no
+    # private generator there.
+    gen = None
+    if world_size > 1 or num_workers > 0:
+        gen = torch.Generator()
+        gen.manual_seed(int(seed) + 7919 * int(getattr(dataset, "seed", 0)) + 1000003 * int(rank))
     loader = torch.utils.data.DataLoader(dataset, batch_size, shuffle=(shuffle and sampler is None), sampler=sampler,
                                          num_workers=num_workers, pin_memory=True, drop_last=drop_last, generator=gen,
                                          worker_init_fn=_seed_worker if num_workers > 0 else None)

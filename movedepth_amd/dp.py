@@ -29,8 +29,14 @@ class GradSync:
     .grad were views of pre-zeroed buffers from the start, so autograd ADDED into them -- one add kernel per parameter and
     backward, 226 launches = 0.70 ms of a 44 ms step, plus 113 MB of zero fill; profiles/r04_ddp_one_rank.txt.)"""
 
-    def __init__(self, params, bucket_mb=32.0, process_group=None):
+    def __init__(self, params, bucket_mb=32.0, process_group=None, direct=None):
         self.pg = process_group
+        # rccl_direct.DirectAllReduce (opt-in): the buckets go through the SAME communicator and stream as the BatchNorm statistics
+        # -- ncclAllReduce on the compute stream, in the program order of the thread that runs backward -- instead of torch's
+        # group and its stream.  One communicator, one stream: the collectives of a step have one total order on every rank
+        # (two communicators on two streams is the documented RCCL hang).  The price is that a bucket's all-reduce no longer
+        # overlaps the backward kernels behind it (4 x 28 MB per step: well under a millisecond over xGMI).
+        self.direct = direct
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         # reverse order ~ order in which backward produces gradients
         self.params = [p for p in reversed(list(params)) if p.requires_grad]
@@ -93,9 +99,15 @@ class GradSync:
             self._pending[bi] -= 1
             if self._pending[bi] == 0 and self.active:
                 self._pack(bi)
-                flat = self.buckets[bi][0]
-                self._handles.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+                self._reduce(bi)
         return hook
+
+    def _reduce(self, bi):
+        flat = self.buckets[bi][0]
+        if self.direct is not None:
+            self.direct(flat)        # on the current (compute) stream; ordered by the stream, nothing to wait for
+        else:
+            self._handles.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
 
     def reset(self):
         """Call before every backward (after zero_grad)."""
@@ -115,7 +127,7 @@ class GradSync:
         for bi, n in enumerate(self._pending):
             if n > 0:
                 self._pack(bi)
-                self._handles.append(dist.all_reduce(self.buckets[bi][0], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+                self._reduce(bi)
         for h in self._handles:
             h.wait()
         inv = 1.0 / self.world

@@ -369,13 +369,14 @@ class HipSyncBatchNorm(nn.Module):
 
     @classmethod
     def from_batchnorm(cls, bn, group=None):
-        m = cls(bn.num_features, bn.eps, 0.1 if bn.momentum is None else bn.momentum)
+        if bn.momentum is None:
+            # cumulative moving average (momentum = 1 / num_batches_tracked): the kernels take a fixed momentum
+            raise NotImplementedError("HipSyncBatchNorm: BatchNorm with momentum=None (cumulative average) is not supported")
+        m = cls(bn.num_features, bn.eps, bn.momentum)
         if bn.affine:
-            with torch.no_grad():
-                m.weight.copy_(bn.weight)
-                m.bias.copy_(bn.bias)
-            m.weight.requires_grad_(bn.weight.requires_grad)
-            m.bias.requires_grad_(bn.bias.requires_grad)
+            # the SAME Parameter objects, as torch's convert_sync_batchnorm does: an optimizer or parameter list built before the
+            # conversion keeps training the tensors the layer uses
+            m.weight, m.bias = bn.weight, bn.bias
         m.running_mean, m.running_var, m.num_batches_tracked = bn.running_mean, bn.running_var, bn.num_batches_tracked
         m.sync_group = group
         m.train(bn.training)
@@ -404,6 +405,13 @@ def convert_hip_sync_batchnorm(module, group=None, fuse_relu=True):
     if isinstance(module, FusedBNReLU3d):
         module.sync_group = group
         return module
+    if isinstance(module, torch.nn.modules.batchnorm._BatchNorm) and not isinstance(module, nn.SyncBatchNorm) and group is not None:
+        # what the kernels do not take (BatchNorm1d, channel counts that are not multiples of 4, no running statistics) must not
+        # silently stay an unsynchronised layer under --ddp --sync_bn: the reference converts EVERY BatchNorm
+        # (trainer.py:69-135, convert_sync_batchnorm) -- so does this, with torch's own module for the leftovers
+        if callable(group) and not isinstance(group, torch.distributed.ProcessGroup):   # a rccl_direct.DirectAllReduce: its torch group
+            group = group.group
+        return nn.SyncBatchNorm.convert_sync_batchnorm(module, group)
     for name, child in list(module.named_children()):
         new = convert_hip_sync_batchnorm(child, group, fuse_relu)
         if new is not child:
@@ -545,7 +553,7 @@ class reg3d(nn.Module):
             if not (x.is_contiguous() or x.is_contiguous(memory_format=torch.channels_last_3d)):
                 x = x.contiguous(memory_format=torch.channels_last_3d)
             c0 = self.conv0.bn(ops.conv3d_16(x, self.conv0.conv.weight, self.lib_conv0_fwd_dgrad))
-            if not isinstance(self.conv0.bn, FusedBNReLU3d):
+            if not (isinstance(self.conv0.bn, FusedBNReLU3d) or getattr(self.conv0.bn, "relu", False)):   # as ConvBnReLU3D.forward
                 c0 = F.relu(c0, inplace=True)
         else:
             x = x.contiguous(memory_format=torch.channels_last_3d) if cl else x.contiguous()

@@ -73,7 +73,12 @@ class Trainer:
         self.rank, self.world_size = 0, 1
         if self.opt.ddp:
             if not dist.is_initialized():
-                dist.init_process_group(backend="gloo" if share_gpu else "nccl")  # "nccl" = RCCL over xGMI
+                # "nccl" = RCCL over xGMI.  An explicit time limit (MD_DIST_TIMEOUT_S, default 600 s): with torch's asynchronous
+                # error handling (on by default) a collective that cannot complete -- a rank died, a mismatch -- ends the
+                # process with an error instead of blocking for ever
+                import datetime
+                dist.init_process_group(backend="gloo" if share_gpu else "nccl",
+                                        timeout=datetime.timedelta(seconds=float(os.environ.get("MD_DIST_TIMEOUT_S", "600"))))
             self.rank, self.world_size = dist.get_rank(), dist.get_world_size()
 
         self.num_scales = len(self.opt.scales)
@@ -104,10 +109,13 @@ class Trainer:
             self.vol_layout = opt.vol_layout
         # the statistics all-reduces of the synchronised BatchNorm layers: straight to RCCL on the compute stream through a
         # communicator of their own when the backend is nccl (rccl_direct: no cross-stream hops, 2 ms per step), else torch's group
+        # (opt-in, MD_DIRECT_RCCL=1; then the gradient buckets go the same way -- one communicator, one stream: rccl_direct's header)
         bn_group = None
+        self.direct_all_reduce = None
         if opt.ddp and opt.sync_bn:
             from . import rccl_direct
-            bn_group = (rccl_direct.make(None) if opt.sync_bn_impl == "hip" else None) or dist.group.WORLD
+            self.direct_all_reduce = rccl_direct.make(None) if opt.sync_bn_impl == "hip" else None
+            bn_group = self.direct_all_reduce or dist.group.WORLD
         self.bn_group = bn_group
         for k, m in self.models.items():
             if opt.sync_bn and (opt.ddp or opt.force_sync_bn):   # also with MD_SHARE_GPU=1: over gloo on CUDA tensors
@@ -170,7 +178,8 @@ class Trainer:
         self.grad_sync = None
         if opt.ddp:
             broadcast_parameters(self.models.values())
-            self.grad_sync = GradSync(self.parameters_to_train + self.mvs_parameters_to_train, opt.grad_bucket_mb)
+            self.grad_sync = GradSync(self.parameters_to_train + self.mvs_parameters_to_train, opt.grad_bucket_mb,
+                                      direct=self.direct_all_reduce)
             opt.log_frequency = max(1, opt.log_frequency // self.world_size)
 
         self.train_sampler = None

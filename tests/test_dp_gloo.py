@@ -176,3 +176,117 @@ def test_direct_rccl_path_declines_without_an_nccl_group():
         assert ops._group_size(f) == 4 and f.seen and f.seen[0] is t
     finally:
         dist.destroy_process_group()
+
+
+def _stage_worker(rank, world, port, q, fail):
+    """rccl_direct.run_stages over gloo: stage 'local_b' raises on the rank named by `fail` ('' = nobody).  The stage behind it is a
+    collective on the group: a rank must reach it only if EVERY rank passed 'local_b'."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    if fail:
+        os.environ["MD_DIRECT_RCCL_FAIL"] = fail
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from movedepth_amd import rccl_direct
+
+    seen = []
+
+    def local_a(st):
+        seen.append("local_a")
+        st["x"] = torch.full((3,), float(rank + 1))
+
+    def local_b(st):
+        seen.append("local_b")
+
+    def collective_c(st):                      # would block for ever if one rank had left after local_b
+        seen.append("collective_c")
+        dist.all_reduce(st["x"])
+
+    st = rccl_direct.run_stages([("local_a", local_a), ("local_b", local_b), ("collective_c", collective_c)], dist.group.WORLD, None, "test")
+    # ranks that fall back keep working on the parent group: one more collective proves nobody is stuck in a stage
+    after = torch.ones(1)
+    dist.all_reduce(after)
+    q.put((rank, st is not None, seen, st["x"].tolist() if st is not None else None, float(after.item())))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fail", ["", "1:local_b", "0:local_a"])
+def test_staged_agreement_one_rank_failure_is_a_group_wide_fallback(fail):
+    """movedepth_amd/rccl_direct.run_stages (what make() is built from): an exception on ONE rank in any stage makes EVERY rank
+    return None at that stage -- no rank enters the next stage's collective alone, no rank blocks.
+    (A rank that dies INSIDE a collective stage, before its collective, cannot be covered by any such protocol -- its peers are
+    already in the call; make()'s collective stages therefore contain nothing but the calls every rank makes, and bench.py's
+    watchdog turns what is left into a non-zero exit code.)"""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_stage_worker, args=(r, world, port, q, fail)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    oks = [r[1] for r in res]
+    assert oks[0] == oks[1], "the ranks must agree on the outcome"
+    assert all(r[4] == 2.0 for r in res), "the parent group must stay usable after a fallback"
+    if not fail:
+        assert oks == [True, True] and all(r[3] == [3.0, 3.0, 3.0] for r in res)
+        assert all(r[2] == ["local_a", "local_b", "collective_c"] for r in res)
+        return
+    assert oks == [False, False]
+    frank, fstage = fail.split(":")
+    order = ["local_a", "local_b", "collective_c"]
+    reached = order[:order.index(fstage) + 1]
+    for r in res:
+        # the failing rank never ran the failing stage's body; the other ran it; nobody went further
+        assert r[2] == (reached[:-1] if r[0] == int(frank) else reached), (fail, r)
+
+
+def _direct_bucket_worker(rank, world, port, q):
+    """GradSync(direct=...): the buckets go through the callable (rccl_direct.DirectAllReduce on the GPU box; here a stand-in with
+    the same interface over gloo) in the order the hooks fire, and the result equals the torch-group path's."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from movedepth_amd.dp import GradSync
+
+    class Direct:
+        size, calls, sizes = world, 0, []
+        def __call__(self, t):
+            self.calls += 1
+            self.sizes.append(t.numel())
+            dist.all_reduce(t)
+            return t
+
+    out = []
+    for use_direct in (False, True):
+        torch.manual_seed(7)
+        net = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.Tanh(), torch.nn.Linear(16, 16), torch.nn.Tanh(), torch.nn.Linear(16, 2))
+        d = Direct() if use_direct else None
+        sync = GradSync(list(net.parameters()), bucket_mb=0.0005, direct=d)
+        x = torch.full((4, 6), float(rank + 1))
+        sync.zero_grad()
+        net(x).square().mean().backward()
+        sync.finish()
+        out.append((torch.cat([p.grad.flatten() for p in net.parameters()]).numpy().copy(), len(sync.buckets), d.calls if d else 0, len(sync._handles)))
+    q.put((rank, out))
+    dist.destroy_process_group()
+
+
+def test_gradsync_buckets_through_a_direct_all_reduce():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_direct_bucket_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    import numpy as np
+    for _, out in res:
+        (g_t, nb, _, _), (g_d, nb_d, calls, handles) = out
+        assert nb == nb_d and nb > 1 and calls == nb and handles == 0   # one direct call per bucket, nothing queued on torch's group
+        assert np.allclose(g_t, g_d, rtol=1e-6, atol=1e-8)
+    assert np.array_equal(res[0][1][1][0], res[1][1][1][0])                # both ranks hold the same mean gradient

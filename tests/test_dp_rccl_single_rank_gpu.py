@@ -67,11 +67,13 @@ def _run(ddp, steps=1):
     return t, losses
 
 
-def _worker(port, q):
+def _worker(port, q, env):
     try:
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
                           HSA_ENABLE_IPC_MODE_LEGACY="0", MD_DP_FORCE_COLLECTIVES="1")
-        os.environ.pop("MD_SHARE_GPU", None)
+        for k in ("MD_SHARE_GPU", "MD_DIRECT_RCCL", "MD_DIRECT_RCCL_FAIL"):
+            os.environ.pop(k, None)
+        os.environ.update(env)
         import torch.distributed as dist
 
         counts = {"all_reduce": 0, "broadcast": 0}
@@ -94,10 +96,27 @@ def _worker(port, q):
         q.put((None, None, None, None, None, None, None, traceback.format_exc()))
 
 
-def test_ddp_step_over_a_single_rank_rccl_group_equals_the_plain_step():
+_PLAIN = []
+
+
+def _plain():
+    if not _PLAIN:
+        t, want_losses = _run(ddp=False)
+        _PLAIN.append((_state(t), want_losses))
+    return _PLAIN[0]
+
+
+@pytest.mark.parametrize("mode", ["torch_group", "direct", "direct_failing_stage"])
+def test_ddp_step_over_a_single_rank_rccl_group_equals_the_plain_step(mode):
+    """torch_group: the default -- every collective through torch.distributed's group.  direct: MD_DIRECT_RCCL=1 -- the BatchNorm
+    statistics AND the gradient buckets as ncclAllReduce on the compute stream through one communicator.  direct_failing_stage: the
+    same with an exception injected into the stage of rccl_direct.make() that takes the communicator handle: the ranks agree to
+    fall back (nothing blocks) and the step runs through torch's group."""
+    env = {"torch_group": {}, "direct": {"MD_DIRECT_RCCL": "1"},
+           "direct_failing_stage": {"MD_DIRECT_RCCL": "1", "MD_DIRECT_RCCL_FAIL": "0:handle"}}[mode]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    p = ctx.Process(target=_worker, args=(_free_port(), q))
+    p = ctx.Process(target=_worker, args=(_free_port(), q, env))
     p.start()
     state, losses, backend, counts, n_buckets, n_sync, direct, err = q.get(timeout=900)
     p.join(timeout=120)
@@ -105,13 +124,16 @@ def test_ddp_step_over_a_single_rank_rccl_group_equals_the_plain_step():
     assert backend == "nccl"
     assert n_sync >= 60                                       # every BatchNorm of the five networks talks to the group
     # one all-reduce per gradient bucket and two per BatchNorm call (>= 100 calls per step: shared encoders run 2-4 times)
-    # the BatchNorm all-reduces go straight to RCCL on the compute stream (movedepth_amd/rccl_direct.py), the buckets through torch
-    assert direct >= 200, direct
-    assert n_buckets >= 2 and counts["all_reduce"] >= n_buckets, (counts, n_buckets)
+    assert n_buckets >= 2
+    if mode == "direct":
+        assert direct >= 200 + n_buckets, (direct, n_buckets)   # statistics and buckets straight to RCCL on the compute stream
+        assert counts["all_reduce"] <= 8, counts                 # torch's group only carried make()'s flag exchanges and its probe
+    else:
+        assert direct == -1, direct                              # no DirectAllReduce in use
+        assert counts["all_reduce"] >= n_buckets + 200, (counts, n_buckets)
     assert counts["broadcast"] >= 100                          # the constructor's weight synchronisation, one call per tensor
 
-    t, want_losses = _run(ddp=False)
-    want = _state(t)
+    want, want_losses = _plain()
     assert abs(losses[0] - want_losses[0]) <= 1e-5 * abs(want_losses[0]), (losses, want_losses)
 
     def rel(keys, a, b):

@@ -24,6 +24,34 @@ def time_fn(fn, iters=50, warm=10):
     return a.elapsed_time(b) * 1e3 / iters  # us
 
 
+def kitti_prior(B, h, w, dev, seed=11):
+    """Driving-scene depth in metres at feature resolution: a ground plane under the horizon (camera 1.65 m above the road,
+    fy = 1.92 h: 6 m at the bottom row, 80 m at the horizon) and smooth 'facades' of 8-80 m above it.  With 1 m of forward motion
+    per frame (kitti_pose) t_z / depth spans 0.0125-0.2: the parallax of KITTI odometry, which BASELINE's own synthetic case
+    (prior U[2,22), translation 3-5 cm) does not have."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    ys = torch.arange(h, dtype=torch.float32).view(1, 1, h, 1)
+    ground = (1.65 * 1.92 * h / (ys - 0.45 * h).clamp(min=1e-3)).clamp(5.0, 80.0).expand(B, 1, h, w)
+    coarse = torch.rand(B, 1, 3, max(2, w // 16), generator=g)
+    facade = 8.0 + 72.0 * torch.nn.functional.interpolate(coarse, size=(h, w), mode="bilinear", align_corners=True)
+    return torch.minimum(ground, facade).contiguous().to(dev)
+
+
+def kitti_pose(B, dev, speed=1.0, seed=13):
+    """Source-from-reference transforms of a car driving straight: +-`speed` m along the optical axis (previous / next frame
+    alternate over the batch), yaw within +-0.01 rad, pitch / roll within +-0.002, a few centimetres sideways and up."""
+    from movedepth_amd.layers import transformation_from_parameters
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    aa = torch.zeros(B, 1, 3)
+    aa[:, 0, 1] = (torch.rand(B, generator=g) * 2 - 1) * 0.01
+    aa[:, 0, 0] = (torch.rand(B, generator=g) * 2 - 1) * 0.002
+    aa[:, 0, 2] = (torch.rand(B, generator=g) * 2 - 1) * 0.002
+    t = torch.zeros(B, 1, 3)
+    t[:, 0, 2] = speed * torch.tensor([1.0 if i % 2 == 0 else -1.0 for i in range(B)])
+    t[:, 0, :2] = (torch.rand(B, 2, generator=g) * 2 - 1) * 0.05
+    return transformation_from_parameters(aa.to(dev), t.to(dev))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--B", type=int, default=6)
@@ -36,7 +64,7 @@ def main():
     ap.add_argument("--layout", default="bgd")
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--dtype", default=os.environ.get("DT", "f32"), choices=["f32", "bf16", "f16"], help="feature-map and volume element type")
-    ap.add_argument("--prior", default=os.environ.get("PRIOR", "white"), choices=["white", "smooth", "const"],
+    ap.add_argument("--prior", default=os.environ.get("PRIOR", "white"), choices=["white", "smooth", "const", "kitti"],
                     help="depth prior: white noise per pixel in [2,22) (adversarial: neighbouring pixels sweep unrelated epipolar "
                          "segments), a smooth field (what the mono decoder produces), or a constant")
     ap.add_argument("--feat", default=os.environ.get("FEAT", "nhwc"), choices=["nchw", "nhwc"],
@@ -60,6 +88,8 @@ def main():
     elif a.prior == "smooth":
         coarse = torch.rand(B, 1, max(2, h // 12), max(2, w // 12), device=dev)
         prior = 2 + 20 * torch.nn.functional.interpolate(coarse, size=(h, w), mode="bilinear", align_corners=True)
+    elif a.prior == "kitti":
+        prior = kitti_prior(B, h, w, dev)
     else:
         prior = torch.full((B, 1, h, w), float(os.environ.get("PRIOR_CONST", "8.0")), device=dev)
     pose = torch.eye(4, device=dev).repeat(B, 1, 1)
@@ -70,6 +100,8 @@ def main():
         gen = torch.Generator(device=dev).manual_seed(7)
         pose = transformation_from_parameters(torch.randn(B, 1, 3, device=dev, generator=gen) * float(os.environ["POSE_ROT"]),
                                               torch.randn(B, 1, 3, device=dev, generator=gen) * float(os.environ.get("POSE_TRANS", "2.0")))
+    if os.environ.get("POSE_KITTI"):
+        pose = kitti_pose(B, dev, float(os.environ["POSE_KITTI"]))
     hyp = ops.schedule_depth_range(prior, D, 0.3)
     kw = dict(prior=prior, ndepth=D, scale_fac=0.3) if a.fused else dict(depth_priors=hyp)
     vol = ops.costvol_grouped(ref, src, K, invK, pose, G, layout=a.layout, **kw)
@@ -126,8 +158,32 @@ def main():
         for nm, fn in (("fwd", fwd), ("bwd", bwd)):
             lib.md_costvol_stats(1, None)
             fn()
+            wgb = (ctypes.c_ulonglong * 8192)()
+            nwg = lib.md_costvol_stats_wg(wgb, 8192)
             buf = (ctypes.c_ulonglong * 8)()
             lib.md_costvol_stats(0, buf)
+            if os.environ.get("MD_CV_WGSTATS"):   # a -DMD_CL_WGSTATS=1 build: 8 numbers per workgroup
+                import numpy as np
+                rec = np.array(list(wgb)[:nwg], dtype=np.float64).reshape(-1, 8)
+                rec = rec[rec[:, 0] > 0]
+                names = ["lifetime", "windows", "gather sub-slices", "gather steps", "cell-change blocks", "lanes in them", "fit attempts", "miss redo"]
+                print("  per-workgroup records %s: %d workgroups" % (nm, len(rec)))
+                for i, n_ in enumerate(names):
+                    c = rec[:, i]
+                    print("    %-20s mean %10.1f  median %10.1f  p90 %10.1f  max %10.1f  corr with lifetime %+.2f" % (
+                        n_, c.mean(), np.median(c), np.percentile(c, 90), c.max(), (np.corrcoef(c, rec[:, 0])[0, 1] if c.std() > 0 else 0.0)))
+                A = np.stack([np.ones(len(rec)), rec[:, 1], rec[:, 3], rec[:, 4], rec[:, 6]], 1)
+                coef, *_ = np.linalg.lstsq(A, rec[:, 0], rcond=None)
+                print("    least squares: lifetime ~ %.0f + %.0f x windows + %.0f x gather steps + %.0f x blocks + %.0f x fit attempts (cycles)" % tuple(coef))
+                if os.environ.get("MD_CV_WGSTATS_DUMP"):
+                    np.save(os.environ["MD_CV_WGSTATS_DUMP"] + "_" + nm + ".npy", rec)
+                lib.md_costvol_stats(0, None)
+                continue
+            life = sorted(x for x in list(wgb)[:nwg] if x)
+            if life:
+                n = len(life)
+                print("  workgroup lifetimes %s (shader cycles): %d workgroups, mean %.0f, median %d, p90 %d, max %d  (max / mean %.2f)" % (
+                    nm, n, sum(life) / n, life[n // 2], life[(9 * n) // 10], life[-1], life[-1] * n / sum(life)))
             v = list(buf)
             if os.environ.get("MD_CV_TIMELINE"):
                 print("  timeline %s (shader cycles of thread 0, summed over workgroups): %s" % (nm, v))
