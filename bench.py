@@ -216,6 +216,61 @@ def gpu_hot_path_ms_per_image(opt, device, iters=20):
                                                     for k, v in per_entry.items()}
 
 
+def parallax_cases(opt, device, iters=24, rotate=8):
+    """The roofline kernels at the workload's launch shape on inputs with the parallax the headline's synthetic batch does not have
+    (BASELINE.md 3 puts translations at 3-5 cm against 2-22 m; a random-init pose network adds little): stand-alone launches,
+    outputs rotating over `rotate` volumes so that a launch never meets its own lines in the Infinity Cache, durations from the
+    dispatch events inside the library.  Cases (movedepth_amd/synthetic.driving_scene; tests/test_hip_parity.py holds the kernels to
+    the oracle on exactly these inputs' kind): a driving scene at 1 m per frame (t_z / depth 0.0125-0.2), the same at 2 m, and
+    'moderate' poses (axis-angle N(0, 0.05^2), translation N(0, 0.3^2)) against a steep smooth prior of 2-22 m.  Secondary figures:
+    the headline `roofline` stays the forward inside the training step."""
+    from movedepth_amd import ops
+    from movedepth_amd.layers import transformation_from_parameters
+    from movedepth_amd.synthetic import driving_scene
+
+    B, D, C, G = opt.batch_size, opt.num_depth_bins, 32, opt.reg3d_c
+    h, w = opt.height // 4, opt.width // 4
+    g = torch.Generator(device=device).manual_seed(5)
+    mk = lambda: torch.randn(B, C, h, w, device=device, generator=g).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    ref, src = mk(), mk()
+    K = torch.tensor([[0.58 * w, 0, 0.5 * w, 0], [0, 1.92 * h, 0.5 * h, 0], [0, 0, 1, 0], [0, 0, 0, 1]], device=device).repeat(B, 1, 1)
+    iK = torch.linalg.pinv(K)
+    coarse = torch.rand(B, 1, max(2, h // 12), max(2, w // 12), device=device, generator=g)
+    smooth = 2 + 20 * torch.nn.functional.interpolate(coarse, size=(h, w), mode="bilinear", align_corners=True)
+    gp = torch.Generator(device=device).manual_seed(7)
+    moderate = transformation_from_parameters(torch.randn(B, 1, 3, device=device, generator=gp) * 0.05,
+                                              torch.randn(B, 1, 3, device=device, generator=gp) * 0.3)
+    cases = {}
+    for name, speed in (("driving scene, 1 m per frame", 1.0), ("driving scene, 2 m per frame", 2.0)):
+        pr, po = driving_scene(B, h, w, speed=speed)
+        cases[name] = (torch.from_numpy(pr).to(device), torch.from_numpy(po).to(device))
+    cases["moderate poses (axis-angle N(0,0.05^2), translation N(0,0.3^2)), smooth prior 2-22 m"] = (smooth, moderate)
+    fbytes = 2 * 4 * B * C * h * w + 4 * B * h * w + 4 * B * D * G * h * w + 192 * B
+    bbytes = 4 * B * D * G * h * w + 2 * 4 * B * C * h * w + 4 * B * h * w + 2 * 4 * B * C * h * w
+    out = {}
+    for name, (prior, pose) in cases.items():
+        keep = [None] * (rotate - 1)
+        vol = ops.costvol_grouped(ref, src, K, iK, pose, G, prior=prior, ndepth=D, scale_fac=0.3, layout="ndhwc")
+        gvol = torch.randn_like(vol)
+        for it in range(iters + 4):
+            if it == 4:
+                torch.cuda.synchronize()
+                ops.enable_library_kernel_timing(ops.TIME_ROOFLINE)
+            with torch.no_grad():
+                keep[it % len(keep)] = ops.costvol_grouped(ref, src, K, iK, pose, G, prior=prior, ndepth=D, scale_fac=0.3, layout="ndhwc")
+            vol.backward(gvol, retain_graph=True)
+        torch.cuda.synchronize()
+        t = ops.library_kernel_times_us(["md_costvol_fwd", "md_costvol_bwd"])
+        ops.enable_library_kernel_timing(False)
+        f, bw = t["md_costvol_fwd"], t["md_costvol_bwd"]
+        out[name] = {"fwd_avg_us": f["avg_us"], "fwd_frac": fbytes / f["avg_us"] * 1e-3 / HBM_PEAK_GBS, "bwd_avg_us": bw["avg_us"],
+                     "bwd_frac": bbytes / bw["avg_us"] * 1e-3 / HBM_PEAK_GBS, "launches": f["launches"]}
+        del keep, vol, gvol
+    return {"shape": "B=%d, %dx%d, D=%d, C=%d, G=%d, fp32, channels-last features and volume, stand-alone launches on %d rotating outputs" % (
+                B, h, w, D, C, G, rotate),
+            "algorithmic_bytes_per_launch": {"fwd": fbytes, "bwd": bbytes}, "peak": HBM_PEAK_GBS, "unit": "GB/s", "cases": out}
+
+
 def start_watchdog(seconds):
     """A hang must become a non-zero exit code.  torch's own watchdog covers collectives issued through torch.distributed (the
     process group is created with a timeout, trainer.py); it does not see a rank that stalls elsewhere, nor ncclAllReduce calls
@@ -352,10 +407,7 @@ def main():
         if k_ in times:
             print("%s: %d launches, %.1f us per step (host-side events around the call)" % (
                 k_, times[k_]["launches"], times[k_]["avg_us"] * times[k_]["launches"] / a.steps), file=sys.stderr)
-    # the backward is two launches: the channels-last kernel and, for samples its pose pre-pass flags, the scatter kernel
-    # (an empty launch of ~5 us when nothing is flagged): both are reported
-    wild = "md_costvol_bwd_wild" + sfx
-    times.update(ops.library_kernel_times_us(["md_costvol_fwd" + sfx, "md_costvol_bwd" + sfx, wild]))
+    times.update(ops.library_kernel_times_us(["md_costvol_fwd" + sfx, "md_costvol_bwd" + sfx]))
     # the convolution kernels: the same dispatch events (main kernel only -- the weight gradients' small finish kernels are
     # separate dispatches); the Python-side figure (argument checks, workspace, finish kernel, launch gaps) is kept beside it
     entry_us = {k_: times[k_]["avg_us"] for k_ in CONV_KERNELS if k_ in times}
@@ -418,8 +470,7 @@ def main():
                          "traffic": traffic, "traffic_from_profile": traffic_profile, "algorithmic_bytes_per_launch": fbytes,
                          "timing": "HIP events inside libmovedepth_hip.so around the kernel launch (md_kernel_timing_*)",
                          "avg_launch_us": kt.get("avg_us"), "min_launch_us": kt.get("min_us"), "median_launch_us": kt.get("median_us"), "launches_timed": kt.get("launches"),
-                         "bwd_avg_launch_us": times.get("md_costvol_bwd" + sfx, {}).get("avg_us"),
-                         "bwd_wild_pose_launch_avg_us": times.get(wild, {}).get("avg_us")},
+                         "bwd_avg_launch_us": times.get("md_costvol_bwd" + sfx, {}).get("avg_us")},
         }
         # the 3-D regulariser's first / last convolutions (hand-off either side of it), same live HIP-event timing (avg_us = the
         # kernel's own dispatch, as rocprofv3 reports it; entry_point_avg_us = events recorded from Python around the whole call):
@@ -438,6 +489,8 @@ def main():
                 e["bound"], e["achieved"], e["peak"], e["unit"] = "hbm", 4 * vox * (opt.reg3d_c + 1) / kc["avg_us"] * 1e-3, HBM_PEAK_GBS, "GB/s"
             e["frac"] = e["achieved"] / e["peak"]
             conv[name] = e
+        if world == 1 and not a.trainer_args and os.environ.get("MD_BENCH_PARALLAX", "1") == "1":
+            out["roofline"]["parallax_cases"] = parallax_cases(opt, dev)
         if conv:
             out["reg3d_handoff_kernels"] = conv
         if photo_in_step:

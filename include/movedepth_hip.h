@@ -73,10 +73,11 @@ int md_costvol_fwd(const float *ref, const float *src, const float *K, const flo
  * gout addressed with the same four strides; d_ref, d_src [B,C,h,w] ([B,h,w,C] with feat_cl) are overwritten (d_src is
  * zeroed, then accumulated with atomics; d_ref is stored directly when every pixel's hypotheses belong to one workgroup,
  * otherwise it takes the same route: then one fill instead of two when d_src == d_ref + B*C*h*w).  Poses that scatter a
- * tile's taps over more source cells than the kernel's window holds (an untrained pose network): with feat_cl the kernel
- * itself switches such hypothesis sub-slices to 16-byte gathers / atomics on L2; with planar features those samples are
- * taken by a second launch of a scatter kernel, chosen per sample by a pose pre-pass on the device (MD_COSTVOL_WILD=0:
- * off; the pre-pass keeps its per-launch flags in a ring of 64 device-global slots: issue these calls from ONE stream). */
+ * tile's taps over more source cells than the kernel's window holds (an untrained pose network, a camera driving into the
+ * scene): with feat_cl the kernel itself switches such hypothesis sub-slices to 16-byte gathers from L2 and queues their
+ * d_src terms in LDS; with planar features they take the kernel's per-tap path.  One launch either way, no state kept
+ * between calls (ABI 16: the pose pre-pass of ABI <= 15, with its ring of device-global flag slots, is gone): re-entrant
+ * across streams like every other entry point. */
 int md_costvol_bwd(const float *gout, long long g_sb, long long g_sd, long long g_sg, long long g_sp, const float *ref,
                    const float *src, const float *K, const float *invK, const float *pose, const float *hyp,
                    const float *prior, const float *ztrans, float scale_fac, int sched_type, int B, int C, int G,

@@ -88,9 +88,6 @@ __device__ __forceinline__ void stio4(io_t *p, float4 v) {
 #endif
 constexpr bool kReferenceOpOrder = MD_COSTVOL_REFERENCE_OP_ORDER != 0;
 
-#ifndef MD_CV_WILD_SLACK
-#define MD_CV_WILD_SLACK 1.5f
-#endif
 constexpr int ITV_MAX = 256;  // hypotheses per D slice served from the LDS interval table
 
 struct CvDims {
@@ -104,14 +101,12 @@ struct CvDims {
     // slices each, workgroups >= nc take 1/fsub of one of the remaining slices (see launch_cl_inst)
     int k1, nc, fsub;
     unsigned long long *stats;   // md_costvol_stats: per-launch counters (null: off)
-    // wide-window fallback (costvol_cl.inc): per-sample flags written by cv_mode_kernel; a kernel processes the samples whose
-    // flag equals its wmode (null: every sample)
-    const unsigned char *wflags;
-    int wmode;
     int fcl;                     // feature maps and their gradients channels-last [B,h,w,C] (channels-last kernels only)
     int xcd_map;                 // item-aligned slices: contiguous ranges per XCD (cv_share)
     float gslack0;               // fcl: ... and by this factor already at the first (whole-slice) attempt: no halving
     float gslack;                // fcl: a sub-slice whose footprint exceeds the window by this factor is gathered from L2 (cl_stage)
+    int shape0;                  // backward: which of the window shapes the fit test tries first (ClShapes, costvol_cl.inc)
+    int min_sub;                 // fcl: shortest hypothesis sub-slice a window is staged for; what does not fit then is gathered from L2
     long long sb, sd, sg, sp;
 };
 
@@ -644,7 +639,6 @@ __global__ __launch_bounds__(256) void costvol_bwd_kernel(const io_t *__restrict
     const long long hi = total * (blockIdx.x + 1) / gridDim.x;
     Seg sg;
     while (next_segment(dm, lo, hi, sg)) {
-    if (dm.wflags && dm.wflags[sg.b] != dm.wmode) continue;   // the channels-last kernel takes this sample (launch_cl)
     for (int i = tid; i < CPW * WP; i += 256) gw[i] = 0.f;
     Walk<FUSED> wk;
     int b, gbase, p, d0, d1, ox, oy;
@@ -732,13 +726,6 @@ int env_int(const char *name, int dflt) {
     return (e && *e) ? atoi(e) : dflt;
 }
 
-// Wild-pose routing: a tile counts against the channels-last backward when its estimated tap footprint exceeds the window by
-// this factor (MD_COSTVOL_WILD_SLACK overrides; see launch_cl)
-float wild_slack() {
-    static const float v = [] { const char *e = getenv("MD_COSTVOL_WILD_SLACK"); const float f = (e && *e) ? (float)atof(e) : MD_CV_WILD_SLACK; return f > 0.f ? f : MD_CV_WILD_SLACK; }();
-    return v;
-}
-
 struct CvPtrs {
     const io_t *gout, *ref, *src;
     const float *K, *invK, *pose, *hyp, *prior, *ztrans;
@@ -778,6 +765,10 @@ int launch_cl_inst(const CvPtrs &q, const CvDims &dm, hipStream_t stream) {
         // two items and stage twice (B=6, 48x160, D=96: 720 workgroups 67.8 us, 512 72.8 us, 1024 82.7 us)
         long long k = (slots + dm.items - 1) / dm.items;
         if (BWD && dm.items * 10 >= slots * 9) k = 1;  // one almost-full round beats two slices per item in two rounds
+        // (Forward with more, shorter slices -- the hardware hands a free slot the next workgroup, which evens out what parallax
+        // makes uneven: measured with 1440 instead of 720 workgroups at B=6, 48x160, D=96: moderate poses 72 -> 64 us, driving scene
+        // 64 -> 62, but sane poses 59.4 -> 60.4, fp16 41 -> 48, config 4's shape 111 -> 126: a staging per slice is not free, and the
+        // sane case is what a training step runs.  Not adopted; profiles/r05_costvol_parallax.txt.)
         if (k > dm.D / 8) k = dm.D / 8;
         if (k < 1) k = 1;
         nwg = (long long)dm.items * k;
@@ -810,7 +801,7 @@ int launch_cl_inst(const CvPtrs &q, const CvDims &dm, hipStream_t stream) {
         // d_src is accumulated with atomics from every workgroup whose window covers a cell: zero it.  d_ref is STORED when a
         // segment is the pixel's only contributor -- true for every segment when each item is one whole-D slice and no other
         // launch shares the samples -- so it only needs the fill otherwise (config 2: 720 items on 768 slots, k = 1).
-        const bool whole = dm2.k1 == 1 && dm2.fsub == 1 && nwg == dm.items && dm.wflags == nullptr && !MD_CL_DREF_ATOMIC;
+        const bool whole = dm2.k1 == 1 && dm2.fsub == 1 && nwg == dm.items && !MD_CL_DREF_ATOMIC;
         const size_t bytes = sizeof(float) * (size_t)dm.B * dm.C * dm.h * dm.w;
         if (!whole && (char *)q.d_ref + bytes == (char *)q.d_src) {
             MD_CHECK_HIP(hipMemsetAsync(q.d_ref, 0, 2 * bytes, stream));
@@ -831,10 +822,6 @@ int launch_cl_inst(const CvPtrs &q, const CvDims &dm, hipStream_t stream) {
     return MD_OK;
 }
 
-// Ring of per-launch flag arrays for the wide-window fallback (device globals: no allocation; a slot is reused 64 launches later)
-constexpr int CV_FLAG_SLOTS = 64, CV_FLAG_MAXB = 1024;
-__device__ unsigned char g_cv_flags[CV_FLAG_SLOTS][CV_FLAG_MAXB];
-
 template <bool BWD>
 int launch_gen1(const CvPtrs &q, CvDims dm, hipStream_t stream, const char *tname);
 
@@ -854,31 +841,10 @@ int launch_cl(const CvPtrs &q, CvDims dm, hipStream_t stream) {
     dm.items = dm.B * dm.tiles;
     dm.dbg = 0;
     dm.stats = md_stats_buffer();
-    dm.wflags = nullptr;
-    dm.wmode = 0;
-    // Wild-pose fallback, backward only (see cv_mode_kernel): a one-workgroup-per-sample pre-pass flags the samples whose taps would
-    // thrash the small window; this file's kernel skips them and the first-generation backward takes them in a second launch.
-    // With sane poses no sample is flagged and the second launch's workgroups exit at once (~5 us).  MD_COSTVOL_WILD=0 switches
-    // the mechanism off, =1 flags every sample.
-    // Planar feature maps only: with channels-last features the kernel itself switches a sub-slice whose footprint exceeds the
-    // window to 16-byte gathers from L2 (cl_stage), no pre-pass, no second launch.
-    const int wild_env = env_int("MD_COSTVOL_WILD", -1);
-    const bool wild_ok = BWD && !dm.fcl && wild_env != 0 && dm.B <= CV_FLAG_MAXB;
-    if (BWD && !dm.fcl && wild_env != 0 && dm.B > CV_FLAG_MAXB) {
-        static bool warned = false;
-        if (!warned) { warned = true; fprintf(stderr, "movedepth_hip: md_costvol_bwd: B=%d > %d, wild-pose routing off\n", dm.B, CV_FLAG_MAXB); }
-    }
-    if (wild_ok) {
-        static std::atomic<unsigned> slot_ctr{0};
-        unsigned char *flags = nullptr;
-        MD_CHECK_HIP(hipGetSymbolAddress((void **)&flags, HIP_SYMBOL(g_cv_flags)));
-        flags += (size_t)(slot_ctr.fetch_add(1) % CV_FLAG_SLOTS) * CV_FLAG_MAXB;
-        // the backward's tile and window: 16 (or 32) x NW pixels + cl_bwd_hx x CL_BWD_HY cells
-        hipLaunchKernelGGL(cv_mode_kernel, dim3(dm.B), dim3(256), 0, stream, q.K, q.invK, q.pose, q.hyp, q.prior, q.ztrans, dm, TW, NW,
-                           wild_slack() * (float)(TW + cl_bwd_hx(NW)), wild_slack() * (float)(NW + CL_BWD_HY), wild_env == 1 ? 1 : 0, flags);
-        MD_CHECK_LAUNCH("md_costvol_bwd (pose pre-pass)");
-        dm.wflags = flags;
-    }
+    // (Planar feature maps with wild poses: rounds 3-4 routed such samples to the first-generation backward through a pose
+    // pre-pass whose per-launch flags lived in a ring of device globals -- hidden state, one stream only.  Gone: the trainer's path
+    // is channels-last features, where the kernel itself gathers what does not fit its window; planar features keep the per-tap
+    // miss path of this kernel for such samples.)
 #define MD_CL_F(N_, LPP_)                                                                                        \
     do {                                                                                                         \
         if (dm.fcl)                                                                                              \
@@ -904,21 +870,26 @@ int launch_cl(const CvPtrs &q, CvDims dm, hipStream_t stream) {
         md_set_error("costvol: no channels-last kernel for C=%d G=%d", dm.C, dm.G);
         return MD_EINVAL;
     }
-    if (rc != MD_OK || !wild_ok) return rc;
-    dm.wmode = 1;
-    return launch_gen1<BWD>(q, dm, stream, MD_CV_STR(MD_CV_NAME(md_costvol_bwd_wild)));
+    return rc;
 }
 
 template <bool BWD>
 int launch(const CvPtrs &q, CvDims dm, hipStream_t stream) {
-    dm.wflags = nullptr;
-    dm.wmode = 0;
     static const float gslack = [] { const char *e = getenv("MD_COSTVOL_GATHER_SLACK"); const float f = (e && *e) ? (float)atof(e) : MD_CL_GATHER_SLACK; return f > 0.f ? f : MD_CL_GATHER_SLACK; }();
     dm.gslack = gslack;
     static const int xcd_map = env_int(BWD ? "MD_COSTVOL_XCD_MAP_BWD" : "MD_COSTVOL_XCD_MAP", 0);
     dm.xcd_map = xcd_map;
     static const float gslack0 = [] { const char *e = getenv("MD_COSTVOL_GATHER_SLACK0"); return (e && *e) ? (float)atof(e) : 1e9f; }();
     dm.gslack0 = gslack0;
+    static const int shape0 = env_int("MD_COSTVOL_BWD_SHAPE0", 0);
+    dm.shape0 = shape0 >= 0 && shape0 < 3 ? shape0 : 0;
+    // 24: a window staged for fewer steps costs more than gathering them (a staging + a d_src window flush are ~25 k cycles of a
+    // backward workgroup, ~10 of a forward one).  At B=6, 48x160, D=96, 8 -> 24: driving scene backward 133 -> 105 us, forward at 2 m
+    // per frame 83 -> 71, moderate poses 73 -> 66 / 132 -> 126; sane and white-noise priors never get there; wild poses 530 -> 540
+    // (profiles/r05_costvol_parallax.txt)
+    static const int min_sub_f = env_int("MD_COSTVOL_MIN_SUB", 24), min_sub_b = env_int("MD_COSTVOL_MIN_SUB_BWD", 24);
+    dm.min_sub = BWD ? min_sub_b : min_sub_f;
+    if (dm.min_sub < 4) dm.min_sub = 4;
     if (cl_eligible(dm, BWD ? (const void *)q.gout : (const void *)q.out)) return launch_cl<BWD>(q, dm, stream);
     if (dm.fcl) {
         md_set_error("costvol: channels-last feature maps need the channels-last volume kernels (volume (B,D,h,w,G) with G = 8 or 16, "

@@ -116,13 +116,16 @@ def _one_step(argv, frame_ids_seed=0):
     return t, outputs, losses, seen
 
 
-def test_config4_train_step_resnet50_320x1024_bf16():
+@pytest.mark.parametrize("batch", [2, 6])
+def test_config4_train_step_resnet50_320x1024_bf16(batch):
+    """BASELINE config 4 end to end; batch 6 is the per-GPU batch the config states (every single-GPU BASELINE
+    config at its stated size), batch 2 the quick variant."""
     t, outputs, losses, seen = _one_step(["--res_arch", "50", "--height", "320", "--width", "1024", "--num_depth_bins", "128",
-                                          "--batch_size", "2", "--amp", "bf16"])
+                                          "--batch_size", str(batch), "--amp", "bf16"])
     assert t.models["mono_encoder"].num_ch_enc[-1] == 2048                       # ResNet-50 trunk
     cv = [s for s in seen if s[0] == "costvol"]
-    assert cv and all(s[1] == torch.bfloat16 and s[2][-2:] == (80, 256) for s in cv), seen
-    assert outputs["depth_mvs"].shape == (2, 320, 1024)
+    assert cv and all(s[1] == torch.bfloat16 and s[2][-2:] == (80, 256) and s[2][0] == batch for s in cv), seen
+    assert outputs["depth_mvs"].shape == (batch, 320, 1024)
     for m in t.models.values():
         assert all(p.grad is not None for p in m.parameters())
 

@@ -24,34 +24,6 @@ def time_fn(fn, iters=50, warm=10):
     return a.elapsed_time(b) * 1e3 / iters  # us
 
 
-def kitti_prior(B, h, w, dev, seed=11):
-    """Driving-scene depth in metres at feature resolution: a ground plane under the horizon (camera 1.65 m above the road,
-    fy = 1.92 h: 6 m at the bottom row, 80 m at the horizon) and smooth 'facades' of 8-80 m above it.  With 1 m of forward motion
-    per frame (kitti_pose) t_z / depth spans 0.0125-0.2: the parallax of KITTI odometry, which BASELINE's own synthetic case
-    (prior U[2,22), translation 3-5 cm) does not have."""
-    g = torch.Generator(device="cpu").manual_seed(seed)
-    ys = torch.arange(h, dtype=torch.float32).view(1, 1, h, 1)
-    ground = (1.65 * 1.92 * h / (ys - 0.45 * h).clamp(min=1e-3)).clamp(5.0, 80.0).expand(B, 1, h, w)
-    coarse = torch.rand(B, 1, 3, max(2, w // 16), generator=g)
-    facade = 8.0 + 72.0 * torch.nn.functional.interpolate(coarse, size=(h, w), mode="bilinear", align_corners=True)
-    return torch.minimum(ground, facade).contiguous().to(dev)
-
-
-def kitti_pose(B, dev, speed=1.0, seed=13):
-    """Source-from-reference transforms of a car driving straight: +-`speed` m along the optical axis (previous / next frame
-    alternate over the batch), yaw within +-0.01 rad, pitch / roll within +-0.002, a few centimetres sideways and up."""
-    from movedepth_amd.layers import transformation_from_parameters
-    g = torch.Generator(device="cpu").manual_seed(seed)
-    aa = torch.zeros(B, 1, 3)
-    aa[:, 0, 1] = (torch.rand(B, generator=g) * 2 - 1) * 0.01
-    aa[:, 0, 0] = (torch.rand(B, generator=g) * 2 - 1) * 0.002
-    aa[:, 0, 2] = (torch.rand(B, generator=g) * 2 - 1) * 0.002
-    t = torch.zeros(B, 1, 3)
-    t[:, 0, 2] = speed * torch.tensor([1.0 if i % 2 == 0 else -1.0 for i in range(B)])
-    t[:, 0, :2] = (torch.rand(B, 2, generator=g) * 2 - 1) * 0.05
-    return transformation_from_parameters(aa.to(dev), t.to(dev))
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--B", type=int, default=6)
@@ -88,8 +60,9 @@ def main():
     elif a.prior == "smooth":
         coarse = torch.rand(B, 1, max(2, h // 12), max(2, w // 12), device=dev)
         prior = 2 + 20 * torch.nn.functional.interpolate(coarse, size=(h, w), mode="bilinear", align_corners=True)
-    elif a.prior == "kitti":
-        prior = kitti_prior(B, h, w, dev)
+    elif a.prior == "kitti":   # driving scene: ground plane + facades (movedepth_amd/synthetic.py driving_scene)
+        from movedepth_amd.synthetic import driving_scene
+        prior = torch.from_numpy(driving_scene(B, h, w)[0]).to(dev)
     else:
         prior = torch.full((B, 1, h, w), float(os.environ.get("PRIOR_CONST", "8.0")), device=dev)
     pose = torch.eye(4, device=dev).repeat(B, 1, 1)
@@ -100,8 +73,9 @@ def main():
         gen = torch.Generator(device=dev).manual_seed(7)
         pose = transformation_from_parameters(torch.randn(B, 1, 3, device=dev, generator=gen) * float(os.environ["POSE_ROT"]),
                                               torch.randn(B, 1, 3, device=dev, generator=gen) * float(os.environ.get("POSE_TRANS", "2.0")))
-    if os.environ.get("POSE_KITTI"):
-        pose = kitti_pose(B, dev, float(os.environ["POSE_KITTI"]))
+    if os.environ.get("POSE_KITTI"):   # +-POSE_KITTI m along the optical axis, small yaw / pitch / roll (driving_scene)
+        from movedepth_amd.synthetic import driving_scene
+        pose = torch.from_numpy(driving_scene(B, h, w, speed=float(os.environ["POSE_KITTI"]))[1]).to(dev)
     hyp = ops.schedule_depth_range(prior, D, 0.3)
     kw = dict(prior=prior, ndepth=D, scale_fac=0.3) if a.fused else dict(depth_priors=hyp)
     vol = ops.costvol_grouped(ref, src, K, invK, pose, G, layout=a.layout, **kw)
@@ -145,7 +119,7 @@ def main():
     tb = time_fn(bwd, a.iters)
     torch.cuda.synchronize()
     sfx = {"f32": "", "bf16": "_bf16", "f16": "_f16"}[a.dtype]
-    lib_t = ops.library_kernel_times_us(["md_costvol_fwd" + sfx, "md_costvol_bwd" + sfx, "md_costvol_bwd_wild" + sfx])
+    lib_t = ops.library_kernel_times_us(["md_costvol_fwd" + sfx, "md_costvol_bwd" + sfx])
     ops.enable_library_kernel_timing(False)
     env = {k: v for k, v in os.environ.items() if k.startswith("MD_")}
     print("costvol B=%d %dx%d D=%d C=%d G=%d fused=%d layout=%s feat=%s dtype=%s prior=%s env=%s" % (B, h, w, D, C, G, a.fused, a.layout, a.feat, a.dtype, a.prior, env))
@@ -166,11 +140,11 @@ def main():
                 import numpy as np
                 rec = np.array(list(wgb)[:nwg], dtype=np.float64).reshape(-1, 8)
                 rec = rec[rec[:, 0] > 0]
-                names = ["lifetime", "windows", "gather sub-slices", "gather steps", "cell-change blocks", "lanes in them", "fit attempts", "miss redo"]
+                names = ["lifetime", "windows", "gather sub-slices / gifts", "gather steps / own range done at", "cell-change blocks", "lanes in them", "fit attempts", "miss redo / ranges taken"]
                 print("  per-workgroup records %s: %d workgroups" % (nm, len(rec)))
                 for i, n_ in enumerate(names):
                     c = rec[:, i]
-                    print("    %-20s mean %10.1f  median %10.1f  p90 %10.1f  max %10.1f  corr with lifetime %+.2f" % (
+                    print("    %-36s mean %10.1f  median %10.1f  p90 %10.1f  max %10.1f  corr with lifetime %+.2f" % (
                         n_, c.mean(), np.median(c), np.percentile(c, 90), c.max(), (np.corrcoef(c, rec[:, 0])[0, 1] if c.std() > 0 else 0.0)))
                 A = np.stack([np.ones(len(rec)), rec[:, 1], rec[:, 3], rec[:, 4], rec[:, 6]], 1)
                 coef, *_ = np.linalg.lstsq(A, rec[:, 0], rcond=None)

@@ -2,7 +2,6 @@
 # Collect PMC counters for the cost-volume kernels (separate passes; --kernel-trace only, as gpurun requires).
 # usage: tools/pmc_costvol.sh <outdir> [bench args...]
 set -u
-export MD_COSTVOL_WILD=0   # no second (empty) launch of the first-generation backward: the counters below are per kernel name
 OUT=$1; shift
 cd /tmp && export TMPDIR=/tmp
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
