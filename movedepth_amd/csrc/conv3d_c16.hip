@@ -373,6 +373,250 @@ __global__ __launch_bounds__(256, 2) void conv3d_c16_fwd_kernel(const float *__r
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Forward / data gradient on the bf16 matrix pipe with fp32 operands cut into three bf16 pieces (channels-last volumes).
+//
+// v_mfma_f32_16x16x4_f32 runs at 1/16 of the bf16 rate (MI355X_MICROARCH.md): the kernel above issues 108 of them (32 cycles
+// each) per 16 output voxels and sits at 67-69 % of that pipe's peak.  A float is the exact sum of three bf16 numbers -- its
+// mantissa's three bytes: hi = x with the low 16 bits cleared, mid = (x - hi) likewise, lo = the rest; every subtraction exact --
+// so x * w = sum of nine bf16 products; the six largest (hi hi, hi mid, mid hi, hi lo, lo hi, mid mid) leave out terms below
+// 2^-23 of the product, the size of fp32's own rounding, and v_mfma_f32_16x16x32_bf16 forms each exactly and adds in fp32.
+// Per K = 32 slice six instructions of ~17 cycles instead of eight of 32 (tools/micro/mfma_bf16x3_probe.hip).
+//
+// What makes it pay is doing the split ONCE per input value and tap ROW, not per tap: the three taps along w of a (kd, kh) row
+// read the same voxels shifted by one, so the input operand (B: K = 2 tap rows x 16 channels, N = 16 voxels along w) is loaded
+// and split once per slice and multiplied with the weights of kw = 0, 1, 2 into three accumulators P_kw[u] = W_kw . x[u]; the
+// output is out[v] = P_0[v-1] + P_1[v] + P_2[v+1] -- a rotation by one lane inside each 16-lane row of the accumulator layout
+// (D[co][voxel]: lane = voxel), two DPP moves per register.  So that no output needs a voxel outside the loaded ones, a tile
+// row is 32 INPUT voxels (two groups of 16, columns tx0-1 .. tx0+30) and 30 outputs; the lanes that close the gap between the
+// two groups take their neighbour's term from the other group (both belong to the same wave).  9 tap rows = 4.5 slices: five,
+// the last one half empty.  Per 16 input voxels: 5 x 3 x 6 = 90 MFMAs (1530 cycles) against 108 x 32 = 3456, 10 ds_read_b128
+// Weights: 5 slices x 3 kw x 3 pieces x 4 registers = 180 VGPRs, resident.
+#ifndef MD_C16_BF3_TH
+#define MD_C16_BF3_TH 4     // tile rows: 4 (one row per wave, 55 KB ring + 15 KB of weights' `lo` pieces: two workgroups per CU) or 8 (two rows per wave, 92 KB, one per CU)
+#endif
+constexpr int B3_TH = MD_C16_BF3_TH, B3_TW = 30, B3_XW = 32, B3_XH = B3_TH + 2, B3_CELLS = B3_XH * B3_XW;
+constexpr bool B3_TWO = B3_TH == 4;   // two workgroups per CU: 256 registers each, the weights' `lo` pieces in LDS
+constexpr int B3_NLD = (B3_CELLS * 4 + 255) / 256;   // float4 pieces per thread per plane
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+struct Bf3 { u32x4 hi, mid, lo; };   // 8 values as packed bf16 pieces (element 2i in the low half of dword i)
+// eight floats -> their three bf16 pieces, by truncation: x = hi + mid + lo exactly (8 + 8 + 8 mantissa bits)
+__device__ __forceinline__ Bf3 bf3_split(const float *x) {
+    Bf3 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        unsigned h[2], m[2], l[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const float v = x[2 * i + e];
+            const unsigned hb = __builtin_bit_cast(unsigned, v) & 0xffff0000u;
+            const float r1 = v - __builtin_bit_cast(float, hb);
+            const unsigned mb = __builtin_bit_cast(unsigned, r1) & 0xffff0000u;
+            const float r2 = r1 - __builtin_bit_cast(float, mb);
+            h[e] = hb; m[e] = mb; l[e] = __builtin_bit_cast(unsigned, r2);
+        }
+        // bytes {a2, a3, b2, b3}: the high halves of a (element 2i) and b (element 2i + 1)
+        r.hi[i] = __builtin_amdgcn_perm(h[1], h[0], 0x07060302u);
+        r.mid[i] = __builtin_amdgcn_perm(m[1], m[0], 0x07060302u);
+        r.lo[i] = __builtin_amdgcn_perm(l[1], l[0], 0x07060302u);
+    }
+    return r;
+}
+__device__ __forceinline__ f32x4 bf3_mfma(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+// the six products of one K = 32 slice: A = weights (rows = output channels), B = input (columns = voxels)
+__device__ __forceinline__ f32x4 bf3_mac(u32x4 whi, u32x4 wmid, u32x4 wlo, const Bf3 &x, f32x4 c) {
+    c = bf3_mfma(wlo, x.hi, c);    // smallest terms first
+    c = bf3_mfma(whi, x.lo, c);
+    c = bf3_mfma(wmid, x.mid, c);
+    c = bf3_mfma(wmid, x.hi, c);
+    c = bf3_mfma(whi, x.mid, c);
+    c = bf3_mfma(whi, x.hi, c);
+    return c;
+}
+// lane j of each 16-lane row <- lane j - 1 (row_ror:1) / j + 1 (row_ror:15) of the same row, wrapping: one DPP move per register.
+// (The components go through named floats: __builtin_bit_cast(int, v[i]) on an element of the vector type read component 0 for
+// every i with this compiler -- ROCm 7.2 -- and the taps along w then mixed the output channels.)
+__device__ __forceinline__ float bf3_rot1(float x, int ctrl_is_ror1) {
+    const int xi = __builtin_bit_cast(int, x);
+    return __builtin_bit_cast(float, ctrl_is_ror1 ? __builtin_amdgcn_update_dpp(0, xi, 0x121, 0xF, 0xF, false)
+                                                  : __builtin_amdgcn_update_dpp(0, xi, 0x12F, 0xF, 0xF, false));
+}
+template <int CTRL>
+__device__ __forceinline__ f32x4 bf3_rot(f32x4 v) {
+    const float a = v.x, b = v.y, c = v.z, d = v.w;
+    return (f32x4){bf3_rot1(a, CTRL == 0x121), bf3_rot1(b, CTRL == 0x121), bf3_rot1(c, CTRL == 0x121), bf3_rot1(d, CTRL == 0x121)};
+}
+
+// The input is cut into its pieces ONCE, when a plane is staged: the LDS image of a plane is three arrays [cell][16 channels] of
+// bf16 (hi, mid, lo: 32 bytes per cell each), and a lane's B operand of a slice is three ds_read_b128.  (First version: fp32
+// planes in LDS, the split in registers at every use -- nine times per element, 2.4 vector instructions per MFMA on top of the
+// MFMAs' own issue slots: the SIMD's issue port, not the matrix pipe, was the limit -- MFMA pipes 45 % busy, 560 us against 580
+// for the fp32-MFMA kernel; profiles/r05_conv3d_c16_bf3.txt.)  92 KB of LDS per workgroup: one workgroup per CU, one wave per
+// SIMD with the whole register file -- all 180 weight registers resident, the next slices' operands requested ahead.
+constexpr int B3_PART_B = B3_CELLS * 32;           // bytes of one piece array of a plane
+constexpr int B3_PLANE_B = 3 * B3_PART_B;          // 30,720 bytes per plane
+__global__ __launch_bounds__(256, B3_TWO ? 2 : 1) void conv3d_c16_fwd_bf3_kernel(const float *__restrict__ in, const float *__restrict__ wt,
+                                                                   long long s_n, long long s_m, long long s_k, int mirror,
+                                                                   float *__restrict__ out, const C16Dims dm) {
+    __shared__ __attribute__((aligned(16))) unsigned char ring[3 * B3_PLANE_B];   // plane P in slot (P + 3) % 3
+    __shared__ u32x4 wlo[B3_TWO ? 15 * 64 : 1];                                    // B3_TWO: the weights' `lo` pieces, [slice * 3 + kw][lane]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, q = lane >> 4, t = q >> 1, o = q & 1;   // voxel / output channel, K octet: tap row t of the slice, channels 8o..8o+7
+    int b, ty0, tx0, d0, d1;
+    c16_item(dm, blockIdx.x, b, ty0, tx0, d0, d1);      // (dm.tiles_x counts 30-column tiles here)
+    tx0 = (tx0 / TW) * B3_TW;
+    ty0 = (ty0 / TH) * B3_TH;
+    const size_t plane = (size_t)dm.H * dm.W;
+    const float *inb = in + (size_t)b * dm.D * plane * CI;
+    float *outb = out + (size_t)b * dm.D * plane * CO;
+    // weights: A operand of slice s, tap column kw: rows = output channel n, K = (tap row 2s + t, input channels 8o..8o+7)
+    Bf3 wr[5][3];
+#pragma unroll
+    for (int s = 0; s < 5; ++s)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const int p = 2 * s + t;       // tap row kd * 3 + kh; 9 = the empty half of the last slice
+            float w8[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = min(p, 8) * 3 + kw;
+                const float v = wt[n * s_n + (long long)(8 * o + j) * s_m + (mirror ? 26 - k : k) * s_k];
+                w8[j] = p < 9 ? v : 0.f;
+            }
+            wr[s][kw] = bf3_split(w8);
+            if (B3_TWO) {   // (every wave holds the same values; published by the first barrier of the march)
+                if (wave == 0) wlo[(s * 3 + kw) * 64 + lane] = wr[s][kw].lo;
+                wr[s][kw].lo = (u32x4){0u, 0u, 0u, 0u};
+            }
+        }
+    // staging: the plane's (rows + 2) x 32 cells (rows ty0-1 .., columns tx0-1 ..), zeros outside the volume, through registers; a thread's
+    // float4 piece (4 channels of a cell) becomes 8 bytes in each of the three piece arrays
+    int ofs[B3_NLD];
+    float4 pre[B3_NLD];
+#pragma unroll
+    for (int i = 0; i < B3_NLD; ++i) {
+        const int idx = tid + i * 256, cell = idx >> 2, qq = idx & 3;
+        const int yy = ty0 - 1 + cell / B3_XW, xx = tx0 - 1 + cell % B3_XW;
+        ofs[i] = (idx < B3_CELLS * 4 && yy >= 0 && yy < dm.H && xx >= 0 && xx < dm.W) ? (yy * dm.W + xx) * 4 + qq : -1;
+    }
+    auto fetch = [&](int P) {
+        const bool inr = P >= 0 && P < dm.D;
+        const float4 *b4 = reinterpret_cast<const float4 *>(inb) + (size_t)(inr ? P : 0) * plane * 4;
+#pragma unroll
+        for (int i = 0; i < B3_NLD; ++i) {
+            if (inr && ofs[i] >= 0) {
+                const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(b4 + ofs[i]));
+                pre[i] = make_float4(v[0], v[1], v[2], v[3]);
+            } else pre[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto stash = [&](int P) {
+        unsigned char *slot = ring + ((P + 3) % 3) * B3_PLANE_B;
+#pragma unroll
+        for (int i = 0; i < B3_NLD; ++i) {
+            const int idx = tid + i * 256;       // piece idx = cell * 4 + quarter: 8 bytes at cell * 32 + quarter * 8 of each array
+            if (idx < B3_CELLS * 4) {
+                const float x4[4] = {pre[i].x, pre[i].y, pre[i].z, pre[i].w};
+                unsigned h[4], m[4], l[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const unsigned hb = __builtin_bit_cast(unsigned, x4[e]) & 0xffff0000u;
+                    const float r1 = x4[e] - __builtin_bit_cast(float, hb);
+                    const unsigned mb = __builtin_bit_cast(unsigned, r1) & 0xffff0000u;
+                    const float r2 = r1 - __builtin_bit_cast(float, mb);
+                    h[e] = hb; m[e] = mb; l[e] = __builtin_bit_cast(unsigned, r2);
+                }
+                uint2 *dst = reinterpret_cast<uint2 *>(slot + idx * 8);
+                dst[0] = make_uint2(__builtin_amdgcn_perm(h[1], h[0], 0x07060302u), __builtin_amdgcn_perm(h[3], h[2], 0x07060302u));
+                dst[B3_PART_B / 8] = make_uint2(__builtin_amdgcn_perm(m[1], m[0], 0x07060302u), __builtin_amdgcn_perm(m[3], m[2], 0x07060302u));
+                dst[2 * (B3_PART_B / 8)] = make_uint2(__builtin_amdgcn_perm(l[1], l[0], 0x07060302u), __builtin_amdgcn_perm(l[3], l[2], 0x07060302u));
+            }
+        }
+    };
+    fetch(d0 - 1); stash(d0 - 1);
+    fetch(d0);     stash(d0);
+    fetch(d0 + 1);
+    for (int d = d0; d < d1; ++d) {
+        stash(d + 1);
+        __syncthreads();
+        if (d + 1 < d1) fetch(d + 2);
+        // this lane's tap row of slice s lives in plane d - 1 + kd, window row (tile row) + kh: byte offset of its cell row's octet
+        int rowofs[5];
+#pragma unroll
+        for (int s = 0; s < 5; ++s) {
+            const int p = min(2 * s + t, 8), kd = p / 3, kh = p - 3 * kd;
+            rowofs[s] = ((d + 2 + kd) % 3) * B3_PLANE_B + kh * (B3_XW * 32) + 16 * o;
+        }
+#pragma unroll 1
+        for (int rr = 0; rr < B3_TH / 4; ++rr) {     // this wave's tile rows
+            const int row = (B3_TH / 4) * wave + rr;
+            f32x4 P[2][3];
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) P[g][kw] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            // five steps = slices, both groups (input voxels 16 g + n of the window row, u = tx0 - 1 + 16 g + n) in each: six
+            // independent accumulators in flight (three left the matrix pipe waiting on its own results: 30 cycles per MFMA
+            // whatever else was done); a step's six operand reads are asked for one step ahead
+            auto load = [&](int sl, int g) {
+                const unsigned char *src = ring + rowofs[sl] + (row * B3_XW + 16 * g + n) * 32;
+                Bf3 x;
+                x.hi = *reinterpret_cast<const u32x4 *>(src);
+                x.mid = *reinterpret_cast<const u32x4 *>(src + B3_PART_B);
+                x.lo = *reinterpret_cast<const u32x4 *>(src + 2 * B3_PART_B);
+                return x;
+            };
+            Bf3 xa = load(0, 0), xb = load(0, 1);
+#pragma unroll
+            for (int sl = 0; sl < 5; ++sl) {
+                Bf3 na = xa, nb = xb;
+                if (sl + 1 < 5) { na = load(sl + 1, 0); nb = load(sl + 1, 1); }
+                __builtin_amdgcn_sched_barrier(0);
+                u32x4 wl[3];
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) wl[kw] = B3_TWO ? wlo[(sl * 3 + kw) * 64 + lane] : wr[sl][kw].lo;
+                // product by product across the six accumulators (smallest terms first)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) { P[0][kw] = bf3_mfma(wl[kw], xa.hi, P[0][kw]); P[1][kw] = bf3_mfma(wl[kw], xb.hi, P[1][kw]); }
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) { P[0][kw] = bf3_mfma(wr[sl][kw].hi, xa.lo, P[0][kw]); P[1][kw] = bf3_mfma(wr[sl][kw].hi, xb.lo, P[1][kw]); }
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) { P[0][kw] = bf3_mfma(wr[sl][kw].mid, xa.mid, P[0][kw]); P[1][kw] = bf3_mfma(wr[sl][kw].mid, xb.mid, P[1][kw]); }
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) { P[0][kw] = bf3_mfma(wr[sl][kw].mid, xa.hi, P[0][kw]); P[1][kw] = bf3_mfma(wr[sl][kw].mid, xb.hi, P[1][kw]); }
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) { P[0][kw] = bf3_mfma(wr[sl][kw].hi, xa.mid, P[0][kw]); P[1][kw] = bf3_mfma(wr[sl][kw].hi, xb.mid, P[1][kw]); }
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) { P[0][kw] = bf3_mfma(wr[sl][kw].hi, xa.hi, P[0][kw]); P[1][kw] = bf3_mfma(wr[sl][kw].hi, xb.hi, P[1][kw]); }
+                __builtin_amdgcn_sched_barrier(0);
+                xa = na; xb = nb;
+            }
+            // out[v] = P_kw0[v - 1] + P_kw1[v] + P_kw2[v + 1]; group 0's lanes are v = n - 1 (lane 0: the halo column, no
+            // output), group 1's v = 15 + n (lane 15: beyond the tile).  Lane 15 of group 0 takes its right neighbour from
+            // group 1's lane 0, lane 0 of group 1 its left neighbour from group 0's lane 15: the wrapped lane of the rotation.
+            const f32x4 l0 = bf3_rot<0x121>(P[0][0]), l1 = bf3_rot<0x121>(P[1][0]);   // lane j <- j - 1, lane 0 <- 15
+            const f32x4 r0 = bf3_rot<0x12F>(P[0][2]), r1 = bf3_rot<0x12F>(P[1][2]);   // lane j <- j + 1, lane 15 <- 0
+            f32x4 rsel = r0, lsel = l1;
+            if (n == 15) rsel = r1;
+            if (n == 0) lsel = l0;
+            const f32x4 o0 = P[0][1] + l0 + rsel;
+            const f32x4 o1 = P[1][1] + lsel + r1;
+            const int yy = ty0 + row;
+            if (yy < dm.H) {
+                const int x0 = tx0 + n - 1, x1 = tx0 + 15 + n;
+                float4 *o4 = reinterpret_cast<float4 *>(outb) + ((size_t)d * plane + (size_t)yy * dm.W) * 4 + q;
+                if (n >= 1 && x0 < dm.W) o4[(size_t)x0 * 4] = make_float4(o0.x, o0.y, o0.z, o0.w);
+                if (n <= 14 && x1 < dm.W) o4[(size_t)x1 * 4] = make_float4(o1.x, o1.y, o1.z, o1.w);
+            }
+        }
+        __syncthreads();
+    }
+}
+
 int c16_dims(const char *fn, int B, int Ci, int Co, int D, int H, int W, C16Dims &dm) {
     MD_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0, "%s: bad dims B=%d D=%d H=%d W=%d", fn, B, D, H, W);
     MD_REQUIRE(Ci == CI && Co == CO, "%s: %d -> %d channels unsupported (16 -> 16 only)", fn, Ci, Co);
@@ -407,6 +651,19 @@ static int c16_launch_fwd(const char *fn, const float *in, const float *wt, long
     MD_REQUIRE(in_planar || ((uintptr_t)in % 16) == 0, "%s: a channels-last input volume must be 16-byte aligned", fn);
     C16Dims dm;
     if (int rc = c16_dims(fn, B, Ci, Co, D, H, W, dm)) return rc;
+    // channels-last in and out (what the trainer runs): the bf16 x 3 kernel, 30-column tiles; MD_C16_BF3=0: the fp32-MFMA kernel
+    static const bool bf3 = [] { const char *e = getenv("MD_C16_BF3"); return !(e && *e == '0'); }();
+    if (bf3 && !in_planar && !out_planar && ((uintptr_t)out % 16) == 0) {
+        C16Dims d3 = dm;
+        d3.tiles_x = md_cdiv(W, B3_TW);
+        d3.tiles = d3.tiles_x * md_cdiv(H, B3_TH);
+        // D slices as for the fp32-MFMA kernels (c16_dims: ~3 workgroups per slot, >= 8 planes each).  Swept at 6x96x48x160
+        // (forward / data gradient, us): 4 slices 492 / 455, 6: 537 / 503, 8: 549 / 481, 12: 597 / 502.
+        const dim3 grid3(B * d3.tiles * d3.dslices), block3(256);
+        MD_LAUNCH_TIMED(fn, conv3d_c16_fwd_bf3_kernel, grid3, block3, 0, (hipStream_t)stream, in, wt, s_n, s_m, s_k, mirror, out, d3);
+        MD_CHECK_LAUNCH(fn);
+        return MD_OK;
+    }
     const dim3 grid(B * dm.tiles * dm.dslices), block(256);
     hipStream_t s = (hipStream_t)stream;
 #define MD_C16_FWD(IP, OP) MD_LAUNCH_TIMED(fn, (conv3d_c16_fwd_kernel<IP, OP>), grid, block, 0, s, in, wt, s_n, s_m, s_k, mirror, out, dm)
