@@ -617,6 +617,162 @@ __global__ __launch_bounds__(256, B3_TWO ? 2 : 1) void conv3d_c16_fwd_bf3_kernel
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Weight gradient on the bf16 matrix pipe, three-piece operands (channels-last volumes).
+//
+// dW[tap][ci][co] = sum over voxels of x[v + tap][ci] * gy[v][co]: D[ci][co] += A[ci][32 voxels] . B[32 voxels][co], K = the 32 voxels of
+// one tile row.  Both operands want, per lane, EIGHT CONSECUTIVE VOXELS OF ONE CHANNEL -- the transpose of what channels-last memory
+// holds:
+//   * x: the staged plane is written to LDS transposed and already cut into its pieces: three arrays [16 channels][6 rows][40] of
+//     bf16 (channel stride 264 elements = 4 banks mod 64: a 16-lane ds_read_b128 touches every bank once).  A lane's operand for tap
+//     column kw starts kw elements into its aligned 8-voxel chunk: one ds_read_b128 + the dword behind it per piece, kw = 2 is the
+//     upper four dwords, kw = 1 a funnel shift (v_alignbit) of neighbouring dwords -- per tap row (kd, kh) 6 reads and 12 vector
+//     instructions feed 3 taps x 6 = 18 MFMAs;
+//   * gy: eight dword loads per lane straight from memory (lane = channel, the wave's 16 channels x 32 voxels are 2 KB contiguous),
+//     cut in registers once per tile row, the B operand of all 27 taps.
+// A wave owns one of the tile's four rows and keeps the 27 taps' 16 x 16 accumulators (108 registers); 162 MFMAs per row and plane.
+// The per-workgroup partial goes out in the layout of the fp32-MFMA kernel above and the same fixed-order fp64 finish adds them.
+constexpr int W3_TH = 4, W3_XH = W3_TH + 2, W3_XWC = TW + 2, W3_PITCH = 40, W3_CH = W3_XH * W3_PITCH + 24;   // elements
+constexpr int W3_PART_B = CI * W3_CH * 2, W3_PLANE_B = 3 * W3_PART_B;     // 8448 / 25344 bytes
+constexpr int W3_NLD = (W3_XH * W3_XWC * 4 + 255) / 256;                  // float4 pieces per thread per plane
+
+__global__ __launch_bounds__(256, 2) void conv3d_c16_bwd_weight_bf3_kernel(const float *__restrict__ x, const float *__restrict__ gy,
+                                                                          float *__restrict__ partial, const C16Dims dm) {
+    __shared__ __attribute__((aligned(16))) unsigned char ring[3 * W3_PLANE_B];   // plane P in slot (P + 3) % 3; reused for the wave reduction
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ch = lane & 15, q = lane >> 4;      // operand row / column (a channel), K octet: voxels 8q .. 8q+7 of the tile row
+    int b, ty0, tx0, d0, d1;
+    c16_item(dm, blockIdx.x, b, ty0, tx0, d0, d1);
+    ty0 = (ty0 / TH) * W3_TH;
+    const size_t plane = (size_t)dm.H * dm.W;
+    const float *xb = x + (size_t)b * dm.D * plane * CI;
+    const float *gyb = gy + (size_t)b * dm.D * plane * CO;
+    // staging of x: cells (rows ty0-1 .., columns tx0-1 ..) x channel quarters through registers; zeros outside the volume
+    int ofs[W3_NLD];
+    float4 pre[W3_NLD];
+#pragma unroll
+    for (int i = 0; i < W3_NLD; ++i) {
+        const int idx = tid + i * 256, cell = idx >> 2, qq = idx & 3;
+        const int yy = ty0 - 1 + cell / W3_XWC, xx = tx0 - 1 + cell % W3_XWC;
+        ofs[i] = (idx < W3_XH * W3_XWC * 4 && yy >= 0 && yy < dm.H && xx >= 0 && xx < dm.W) ? (yy * dm.W + xx) * 4 + qq : -1;
+    }
+    auto fetch = [&](int P) {
+        const bool inr = P >= 0 && P < dm.D;
+        const float4 *b4 = reinterpret_cast<const float4 *>(xb) + (size_t)(inr ? P : 0) * plane * 4;
+#pragma unroll
+        for (int i = 0; i < W3_NLD; ++i) {
+            if (inr && ofs[i] >= 0) {
+                const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(b4 + ofs[i]));
+                pre[i] = make_float4(v[0], v[1], v[2], v[3]);
+            } else pre[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto stash = [&](int P) {
+        unsigned short *slot = reinterpret_cast<unsigned short *>(ring + ((P + 3) % 3) * W3_PLANE_B);
+#pragma unroll
+        for (int i = 0; i < W3_NLD; ++i) {
+            const int idx = tid + i * 256, cell = idx >> 2, qq = idx & 3;
+            if (idx < W3_XH * W3_XWC * 4) {
+                const int e0 = (4 * qq) * W3_CH + (cell / W3_XWC) * W3_PITCH + cell % W3_XWC;   // element of channel 4 qq in a piece array
+                const float x4[4] = {pre[i].x, pre[i].y, pre[i].z, pre[i].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const unsigned hb = __builtin_bit_cast(unsigned, x4[e]) & 0xffff0000u;
+                    const float r1 = x4[e] - __builtin_bit_cast(float, hb);
+                    const unsigned mb = __builtin_bit_cast(unsigned, r1) & 0xffff0000u;
+                    const float r2 = r1 - __builtin_bit_cast(float, mb);
+                    slot[e0 + e * W3_CH] = (unsigned short)(hb >> 16);
+                    slot[W3_PART_B / 2 + e0 + e * W3_CH] = (unsigned short)(mb >> 16);
+                    slot[W3_PART_B + e0 + e * W3_CH] = (unsigned short)(__builtin_bit_cast(unsigned, r2) >> 16);
+                }
+            }
+        }
+    };
+    f32x4 acc[NTAP];
+#pragma unroll
+    for (int k = 0; k < NTAP; ++k) acc[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    fetch(d0 - 1); stash(d0 - 1);
+    fetch(d0);     stash(d0);
+    fetch(d0 + 1);
+    const int yy = ty0 + wave;          // this wave's tile row
+    for (int d = d0; d < d1; ++d) {
+        // the row's gy operand: voxels tx0 + 8q .. + 7 of channel `ch`, requested before the barrier
+        float g8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int xx = tx0 + 8 * q + j;
+            g8[j] = (yy < dm.H && xx < dm.W) ? __builtin_nontemporal_load(gyb + ((size_t)d * plane + (size_t)yy * dm.W + xx) * CO + ch) : 0.f;
+        }
+        stash(d + 1);
+        __syncthreads();
+        if (d + 1 < d1) fetch(d + 2);
+        const Bf3 gs = bf3_split(g8);
+        // nine tap rows (kd, kh); a row's raw reads: per piece the aligned 8-voxel chunk of channel `ch` at window row wave + kh,
+        // column 8q, and the dword behind it.  (Asked for one row ahead and pinned there with sched_barrier: 544 against 528 us --
+        // two waves per SIMD cover the LDS round trips by themselves here, the pinning only costs registers.)
+        struct Raw { u32x4 a[3]; unsigned t[3]; };
+        auto rload = [&](int p) {
+            const int kd = p / 3, kh = p - 3 * kd;
+            const unsigned char *src = ring + ((d + 2 + kd) % 3) * W3_PLANE_B + (ch * W3_CH + (wave + kh) * W3_PITCH + 8 * q) * 2;
+            Raw r;
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) {
+                r.a[pc] = *reinterpret_cast<const u32x4 *>(src + pc * W3_PART_B);
+                r.t[pc] = *reinterpret_cast<const unsigned *>(src + pc * W3_PART_B + 16);
+            }
+            return r;
+        };
+#pragma unroll
+        for (int p = 0; p < 9; ++p) {
+            const Raw cur = rload(p);
+            // tap columns kw = 0, 1, 2: voxels 8q + kw .. + 7 of the window row -- the chunk, a funnel shift, the upper dwords
+            u32x4 x0[3], x1[3], x2[3];
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) {
+                const u32x4 a = cur.a[pc];
+                const unsigned a4 = cur.t[pc];
+                x0[pc] = a;
+                x1[pc] = (u32x4){__builtin_amdgcn_alignbit(a[1], a[0], 16), __builtin_amdgcn_alignbit(a[2], a[1], 16),
+                                 __builtin_amdgcn_alignbit(a[3], a[2], 16), __builtin_amdgcn_alignbit(a4, a[3], 16)};
+                x2[pc] = (u32x4){a[1], a[2], a[3], a4};
+            }
+            const int k0 = p * 3;
+            // A = x (rows = input channel), B = gy (columns = output channel); six products per tap (pieces 0 / 1 / 2 = hi / mid / lo),
+            // the three taps interleaved, smallest terms first
+            acc[k0] = bf3_mfma(x0[2], gs.hi, acc[k0]); acc[k0 + 1] = bf3_mfma(x1[2], gs.hi, acc[k0 + 1]); acc[k0 + 2] = bf3_mfma(x2[2], gs.hi, acc[k0 + 2]);
+            acc[k0] = bf3_mfma(x0[0], gs.lo, acc[k0]); acc[k0 + 1] = bf3_mfma(x1[0], gs.lo, acc[k0 + 1]); acc[k0 + 2] = bf3_mfma(x2[0], gs.lo, acc[k0 + 2]);
+            acc[k0] = bf3_mfma(x0[1], gs.mid, acc[k0]); acc[k0 + 1] = bf3_mfma(x1[1], gs.mid, acc[k0 + 1]); acc[k0 + 2] = bf3_mfma(x2[1], gs.mid, acc[k0 + 2]);
+            acc[k0] = bf3_mfma(x0[1], gs.hi, acc[k0]); acc[k0 + 1] = bf3_mfma(x1[1], gs.hi, acc[k0 + 1]); acc[k0 + 2] = bf3_mfma(x2[1], gs.hi, acc[k0 + 2]);
+            acc[k0] = bf3_mfma(x0[0], gs.mid, acc[k0]); acc[k0 + 1] = bf3_mfma(x1[0], gs.mid, acc[k0 + 1]); acc[k0 + 2] = bf3_mfma(x2[0], gs.mid, acc[k0 + 2]);
+            acc[k0] = bf3_mfma(x0[0], gs.hi, acc[k0]); acc[k0 + 1] = bf3_mfma(x1[0], gs.hi, acc[k0 + 1]); acc[k0 + 2] = bf3_mfma(x2[0], gs.hi, acc[k0 + 2]);
+        }
+        __syncthreads();  // slot (d+2)%3 == (d-1)%3 is rewritten at the top of the next step
+    }
+    // sum the 4 waves through LDS (two waves' accumulators fit at a time), wave 0 writes the workgroup's partial
+    f32x4 *red = reinterpret_cast<f32x4 *>(ring);  // [2][NTAP][64]
+    if (wave >= 2) {
+#pragma unroll
+        for (int k = 0; k < NTAP; ++k) red[((wave - 2) * NTAP + k) * 64 + lane] = acc[k];
+    }
+    __syncthreads();
+    if (wave < 2) {
+#pragma unroll
+        for (int k = 0; k < NTAP; ++k) acc[k] += red[(wave * NTAP + k) * 64 + lane];
+    }
+    __syncthreads();
+    if (wave == 1) {
+#pragma unroll
+        for (int k = 0; k < NTAP; ++k) red[k * 64 + lane] = acc[k];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        f32x4 *out = reinterpret_cast<f32x4 *>(partial) + (size_t)blockIdx.x * NTAP * 64;
+#pragma unroll
+        for (int k = 0; k < NTAP; ++k) out[k * 64 + lane] = acc[k] + red[k * 64 + lane];
+    }
+}
+
 int c16_dims(const char *fn, int B, int Ci, int Co, int D, int H, int W, C16Dims &dm) {
     MD_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0, "%s: bad dims B=%d D=%d H=%d W=%d", fn, B, D, H, W);
     MD_REQUIRE(Ci == CI && Co == CO, "%s: %d -> %d channels unsupported (16 -> 16 only)", fn, Ci, Co);
@@ -687,9 +843,14 @@ int md_conv3d_c16_bwd_data(const float *gy, const float *wt, long long w_stride_
                           D, H, W, stream);
 }
 
+// the bf16 x 3 weight gradient's tiles are 4 rows high: twice the workgroups (and partials) of the fp32-MFMA kernel's
+static void c16_dims_w3(C16Dims &dm, int H) { dm.tiles = dm.tiles_x * md_cdiv(H, W3_TH); }
+static bool c16_w3_on() { static const bool v = [] { const char *e = getenv("MD_C16_BF3_WGRAD"); return !(e && *e == '0'); }(); return v; }
+
 size_t md_conv3d_c16_bwd_weight_ws_bytes(int B, int D, int H, int W) {
     C16Dims dm;
     if (c16_dims("md_conv3d_c16_bwd_weight_ws_bytes", B, CI, CO, D, H, W, dm)) return 0;
+    c16_dims_w3(dm, H);     // the larger of the two kernels' needs
     return (size_t)B * dm.tiles * dm.dslices * NTAP * CI * CO * sizeof(float);
 }
 
@@ -701,11 +862,14 @@ int md_conv3d_c16_bwd_weight(const float *x, int x_planar, const float *gy, floa
                "md_conv3d_c16_bwd_weight: a channels-last x and ws must be 16-byte aligned");
     C16Dims dm;
     if (int rc = c16_dims("md_conv3d_c16_bwd_weight", B, Ci, Co, D, H, W, dm)) return rc;
+    const bool w3 = c16_w3_on() && !x_planar;   // channels-last x (what the trainer runs): the bf16 x 3 kernel; MD_C16_BF3_WGRAD=0: fp32 MFMA
+    if (w3) c16_dims_w3(dm, H);
     const int nwg = B * dm.tiles * dm.dslices;
     MD_REQUIRE(ws_bytes >= (size_t)nwg * NTAP * CI * CO * sizeof(float), "md_conv3d_c16_bwd_weight: workspace too small (%zu bytes)", ws_bytes);
     hipStream_t s = (hipStream_t)stream;
     float *partial = (float *)ws;
-    if (x_planar) MD_LAUNCH_TIMED("md_conv3d_c16_bwd_weight", conv3d_c16_bwd_weight_kernel<true>, dim3(nwg), dim3(256), 0, s, x, gy, partial, dm);
+    if (w3) MD_LAUNCH_TIMED("md_conv3d_c16_bwd_weight", conv3d_c16_bwd_weight_bf3_kernel, dim3(nwg), dim3(256), 0, s, x, gy, partial, dm);
+    else if (x_planar) MD_LAUNCH_TIMED("md_conv3d_c16_bwd_weight", conv3d_c16_bwd_weight_kernel<true>, dim3(nwg), dim3(256), 0, s, x, gy, partial, dm);
     else MD_LAUNCH_TIMED("md_conv3d_c16_bwd_weight", conv3d_c16_bwd_weight_kernel<false>, dim3(nwg), dim3(256), 0, s, x, gy, partial, dm);
     MD_CHECK_LAUNCH("md_conv3d_c16_bwd_weight");
     hipLaunchKernelGGL(conv3d_c16_bwd_weight_finish_kernel, dim3(NTAP * 256 / 16), dim3(256), 0, s, partial, nwg, dw_stride_co,
