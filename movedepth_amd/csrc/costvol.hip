@@ -812,10 +812,24 @@ int launch_cl_inst(const CvPtrs &q, const CvDims &dm, hipStream_t stream) {
     }
     hipEvent_t ev0, ev1;
     md_timing_pair(tname, &ev0, &ev1);
-    if constexpr (BWD)
+    if constexpr (BWD) {
+        // MD_COSTVOL_GATHER_TABLE=1: the build of the 16 x 4-tile kernel whose gather mode merges a tile's d_src terms per source cell
+        // in LDS before they leave the CU (costvol_cl.inc, TAB).  For the wild poses of an untrained pose network, where the launch is
+        // bound by the L2's float-atomic rate: 540 -> 314 us at B=6, 48x160, D=96.  Its own instantiation and opt-in because the table
+        // code costs the kernel that carries it: 168 registers + 3 spilled (scratch set-up per launch) and a slower gather walk when
+        // the table does not pay -- sane poses 61.7 -> 65 us, driving scene 106 -> 123, moderate 122 -> 138 (profiles/r05_costvol_table.txt).
+        const bool table = env_int("MD_COSTVOL_GATHER_TABLE", 0) != 0;   // (read per launch: a trainer may switch it once its poses have settled)
+        if constexpr (FCL && LPP == 4 && NW == 4 && N <= 2) {
+            if (table) {
+                hipExtLaunchKernelGGL((cl_bwd_kernel<N, LPP, NW, FUSED, FCL, true>), grid, block, 0, stream, ev0, ev1, 0, q.gout, q.ref, q.src,
+                                      q.K, q.invK, q.pose, q.hyp, q.prior, q.ztrans, q.d_ref, q.d_src, dm2);
+                MD_CHECK_LAUNCH("md_costvol_bwd (channels-last, cell table)");
+                return MD_OK;
+            }
+        }
         hipExtLaunchKernelGGL((cl_bwd_kernel<N, LPP, NW, FUSED, FCL>), grid, block, 0, stream, ev0, ev1, 0, q.gout, q.ref, q.src,
                               q.K, q.invK, q.pose, q.hyp, q.prior, q.ztrans, q.d_ref, q.d_src, dm2);
-    else
+    } else
         hipExtLaunchKernelGGL((cl_fwd_kernel<N, LPP, NW, FUSED, FCL>), grid, block, 0, stream, ev0, ev1, 0, q.ref, q.src, q.K,
                               q.invK, q.pose, q.hyp, q.prior, q.ztrans, q.out, dm2);
     MD_CHECK_LAUNCH(BWD ? "md_costvol_bwd (channels-last)" : "md_costvol_fwd (channels-last)");

@@ -407,6 +407,43 @@ def test_costvol_wild_poses_backward_fallback_vs_oracle(ops, oracle_lib, feat):
     assert_close(host(s.grad), exp_dsrc, what="d_src")
 
 
+@pytest.mark.parametrize("case", ["wild", "moderate", "driving_2m"])
+def test_costvol_backward_cell_table_vs_oracle(ops, oracle_lib, case, monkeypatch):
+    """MD_COSTVOL_GATHER_TABLE=1: the backward instantiation whose gather mode merges a tile's d_src terms per source cell in LDS
+    (csrc/costvol_cl.inc, TAB: cell-keyed slots in the idle d_src window, a taken slot falls back to the queue, the table leaves the CU
+    every 32 steps) at config 2's launch shape, channels-last features: wild poses (every slice gathered, slots contended), moderate
+    poses and the driving scene at 2 m per frame (windows and gathered ranges in one workgroup).  White-noise features and gradient.
+    Reference: autograd of layers.py:791 (zeros padding, per-tap drop)."""
+    from movedepth_amd.synthetic import driving_scene
+    rng = np.random.default_rng(79)
+    B, C, G, h, w, D = 6, 32, 16, 48, 160, 96
+    ref = rng.standard_normal((B, C, h, w)).astype(np.float32)
+    src = rng.standard_normal((B, C, h, w)).astype(np.float32)
+    K, invK = kitti_K(h, w, B)
+    if case == "driving_2m":
+        prior, pose = driving_scene(B, h, w, speed=2.0)
+    else:
+        prior = (2 + 20 * smooth_field(rng, (B, 1, h, w), 12, 0, 1)).astype(np.float32)
+        pose = rand_pose(oracle_lib, rng, B, 0.3, 2.0) if case == "wild" else rand_pose(oracle_lib, rng, B, 0.05, 0.3)
+    hyp = oracle_lib.schedule_depth_range(prior, D, 0.3, None, "inverse")
+    gout = rng.standard_normal((B, D, G, h, w)).astype(np.float32)
+    exp_dref, exp_dsrc = oracle_lib.costvol_grouped_bwd(gout, ref, src, K, invK, hyp, pose)
+    monkeypatch.setenv("MD_COSTVOL_GATHER_TABLE", "1")
+    ops.enable_library_kernel_timing(True)
+    try:
+        r, s = feat_dev(ref, "nhwc"), feat_dev(src, "nhwc")
+        vol = ops.costvol_grouped(r, s, dev(K), dev(invK), dev(pose), G, prior=dev(prior), ndepth=D, scale_fac=0.3, type="inverse",
+                                  layout="ndhwc")
+        vol.backward(dev(gout))
+        torch.cuda.synchronize()
+        t = ops.library_kernel_times_us(["md_costvol_bwd"])
+    finally:
+        ops.enable_library_kernel_timing(False)
+    assert t["md_costvol_bwd"]["launches"] == 1, t
+    assert_close(host(r.grad), exp_dref, what="d_ref")
+    assert_close(host(s.grad), exp_dsrc, what="d_src")
+
+
 @pytest.mark.parametrize("feat", FEATS)
 def test_costvol_full_size_properties(ops, feat):
     """BASELINE config 2 size (B=6, 48x160, D=96, C=32, G=16): size-independent properties, beside the oracle comparison of
