@@ -41,6 +41,9 @@ constexpr int BT_W = 32, BT_H = 8;                                              
 #ifndef MD_PHOTO_BWD_WAVES
 #define MD_PHOTO_BWD_WAVES 4     // waves per SIMD the backward is compiled for (up to two source frames): 128 registers, 9 spilled at F = 2; 3: 135, none (A/B: 201 -> 177 us)
 #endif
+#ifndef MD_PHOTO_FWD_WAVES
+#define MD_PHOTO_FWD_WAVES 3     // waves per SIMD the forward is compiled for (up to two source frames); A/B: tools/ab_build.sh
+#endif
 #ifndef MD_PHOTO_BWD_ONEPASS
 #define MD_PHOTO_BWD_ONEPASS 1   // coefficient maps of all frames in one pass (photo_bwd_kernel); 0: one masked pass per frame (A/B)
 #endif
@@ -122,7 +125,7 @@ __device__ __forceinline__ void load_cams(const md_photo_desc &a, int b, float *
 
 // ------------------------------------------------------------------------------------------------ forward
 template <int F, bool IDENT>
-__global__ __launch_bounds__(256) void photo_fwd_kernel(const md_photo_desc a, float *__restrict__ ws) {
+__global__ __launch_bounds__(256, (F <= 2 ? MD_PHOTO_FWD_WAVES : 2)) void photo_fwd_kernel(const md_photo_desc a, float *__restrict__ ws) {
     extern __shared__ float4 lds[];
     float4 *tg = lds;          // target, halo 1
     float4 *wp = lds + FP_N;   // wp[f * FP_N + i]: prediction of frame f
@@ -250,8 +253,9 @@ __global__ __launch_bounds__(256) void photo_fwd_kernel(const md_photo_desc a, f
                         ss += fminf(fmaxf(sv, 0.f), 1.f);  // torch.clamp(., 0, 1)
                     }
                 }
-                l1 /= 3.f;
-                ss /= 3.f;
+                // mean over the three channels: an IEEE quotient by the constant 3 (div_by: 3 instructions, same bits)
+                l1 = div_by(l1, 3.f, 1.f / 3.f);
+                ss = div_by(ss, 3.f, 1.f / 3.f);
                 lossf[k][f] = use_ssim ? ssim_w * ss + (1.f - ssim_w) * l1 : l1;
             }
         }

@@ -77,6 +77,19 @@ def main():
         f = timeit(lambda: fn(False), a.iters)
         fb = timeit(lambda: fn(True), a.iters)
         print("  %-52s fwd %7.1f us   fwd+bwd %7.1f us (wall, incl. Python)" % (name, f, fb))
+    # the kernels' own durations (HIP events inside the library around each launch), per training step's worth of calls: identity +
+    # mono group + MVS group, forward and backward
+    ops.enable_library_kernel_timing(True)
+    n = 20
+    for _ in range(n):
+        mono(True)
+        mvs(True)
+    torch.cuda.synchronize()
+    t = ops.library_kernel_times_us(["md_photo_fwd", "md_photo_bwd"])
+    ops.enable_library_kernel_timing(False)
+    for k, v in t.items():
+        print("  kernel only %-14s %7.1f us per step's worth of calls (%d dispatches each, avg %.1f us)"
+              % (k, v["avg_us"] * v["launches"] / n, v["launches"] // n, v["avg_us"]))
 
 
 if __name__ == "__main__":
