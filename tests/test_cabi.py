@@ -69,3 +69,11 @@ def test_ops_refuse_cpu_tensors():
 
     with pytest.raises(_lib.MovedepthHipError):
         ops.reprojection_loss(torch.zeros(1, 3, 8, 8), torch.zeros(1, 3, 8, 8))
+
+
+def test_graft_entry_build():
+    """__graft_entry__.build() is the driver's "does it build" check: make (a no-op on an up-to-date tree), the C oracle, the import
+    and its own ABI assertion must pass here -- a stale version number in it fails the round's build check, not a test."""
+    import __graft_entry__
+
+    __graft_entry__.build()
