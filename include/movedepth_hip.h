@@ -75,7 +75,10 @@ int md_costvol_fwd(const float *ref, const float *src, const float *K, const flo
  * otherwise it takes the same route: then one fill instead of two when d_src == d_ref + B*C*h*w).  Poses that scatter a
  * tile's taps over more source cells than the kernel's window holds (an untrained pose network, a camera driving into the
  * scene): with feat_cl the kernel itself switches such hypothesis sub-slices to 16-byte gathers from L2 and queues their
- * d_src terms in LDS; with planar features they take the kernel's per-tap path.  One launch either way, no state kept
+ * d_src terms in LDS; with planar features they take the kernel's per-tap path.  MD_COSTVOL_GATHER_TABLE=1 in the environment
+ * (read at every call) selects the build of the fp32 / 2-byte 16 x 4-tile kernel that also merges those terms per source cell in LDS
+ * before they leave the CU: for phases with wild poses (5.1x instead of 8.7x the sane time), ~7 % slower when poses are sane; same
+ * results to float-atomic ordering.  One launch either way, no state kept
  * between calls (ABI 16: the pose pre-pass of ABI <= 15, with its ring of device-global flag slots, is gone): re-entrant
  * across streams like every other entry point. */
 int md_costvol_bwd(const float *gout, long long g_sb, long long g_sd, long long g_sg, long long g_sp, const float *ref,

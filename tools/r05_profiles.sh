@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-5 profile bundle (run on the GPU box through gpurun): tools/r05_profiles.sh <stage ...>
-#   stages: test bench step pmc parallax convpmc cfg n8
+#   stages: test bench step pmc parallax photopmc convpmc cfg n8
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 O=$GRAFT_REPO_ROOT/gpurun_out/r05_profiles; mkdir -p $O
@@ -25,6 +25,8 @@ parallax)
         env ${c##*|} MD_CV_STATS=1 $B $cfg 2>&1 | grep "kernel only\|stats" | sed 's/(dispatch start.stop events inside the library) //'
       done
     done; } > $O/r05_parallax_final.txt 2>&1; tail -30 $O/r05_parallax_final.txt ;;
+photopmc)
+  timeout 1500 bash tools/pmc_photo.sh $O/r05_photo_pmc.txt > $O/photopmc.log 2>&1; head -3 $O/r05_photo_pmc.txt ;;
 convpmc)
   SCRIPTS=bench_conv3d_c16 timeout 1200 bash tools/pmc_conv.sh $O/r05_conv3d_c16_pmc.txt > /dev/null 2>&1; grep "^conv\|=>" $O/r05_conv3d_c16_pmc.txt
   { for v in "MD_C16_BF3=1 MD_C16_BF3_WGRAD=1" "MD_C16_BF3=0 MD_C16_BF3_WGRAD=0"; do echo "== $v"; env $v NO_LIB=1 timeout 600 python tools/bench_conv3d_c16.py 2>&1 | grep "fwd\|bwd-"; done; } > $O/r05_conv3d_c16_standalone.txt 2>&1; cat $O/r05_conv3d_c16_standalone.txt ;;
