@@ -68,6 +68,10 @@ SIGNATURES = {
     "md_conv3d_c16_bwd_data": (_i, [_vp, _vp, _ll, _ll, _ll, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "md_conv3d_c16_bwd_weight_ws_bytes": (_sz, [_i, _i, _i, _i]),
     "md_conv3d_c16_bwd_weight": (_i, [_vp, _i, _vp, _vp, _ll, _ll, _ll, _vp, _sz, _i, _i, _i, _i, _i, _i, _vp]),
+    "md_conv3d_cb_fwd": (_i, [_vp, _vp, _ll, _ll, _ll, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "md_conv3d_cb_bwd_data": (_i, [_vp, _vp, _ll, _ll, _ll, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "md_conv3d_cb_bwd_weight_ws_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
+    "md_conv3d_cb_bwd_weight": (_i, [_vp, _vp, _vp, _ll, _ll, _ll, _vp, _sz, _i, _i, _i, _i, _i, _i, _vp]),
     "md_bn_relu_ws_bytes": (_sz, []),
     "md_bn_relu_stats": (_i, [_vp, _ll, _i, _vp, _vp, _vp]),
     "md_bn_relu_finalize": (_i, [_vp, _ll, _i, _f, _f, _vp, _vp, _vp, _vp, _vp]),

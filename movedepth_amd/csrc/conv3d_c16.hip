@@ -47,6 +47,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 struct C16Dims {
     int B, D, H, W;
     int tiles_x, tiles, dslices, planes;
+    // bf16 x 3 kernels only: a 16-channel BLOCK of wider channels-last volumes (md_conv3d_cb_*: Ci, Co multiples of 16 as sums over
+    // 16 x 16 blocks).  Record pitch and the block's offset in float4 units, for the input (x / gy) and the output (y / dx) side;
+    // acc: the output block is added to, not stored (the second and later input blocks of an output block).  4, 0, 4, 0, 0: plain 16 -> 16.
+    int ip4, io4, op4, oo4, acc;
+    int nob;   // forward / data gradient: output blocks covered by ONE launch (workgroup -> block blockIdx % nob; oo4 and the weights' offset follow)
 };
 
 __device__ __forceinline__ void c16_item(const C16Dims &dm, int item, int &b, int &ty0, int &tx0, int &d0, int &d1) {
@@ -467,12 +472,14 @@ __global__ __launch_bounds__(256, B3_TWO ? 2 : 1) void conv3d_c16_fwd_bf3_kernel
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, q = lane >> 4, t = q >> 1, o = q & 1;   // voxel / output channel, K octet: tap row t of the slice, channels 8o..8o+7
     int b, ty0, tx0, d0, d1;
-    c16_item(dm, blockIdx.x, b, ty0, tx0, d0, d1);      // (dm.tiles_x counts 30-column tiles here)
+    const int ob = dm.nob > 1 ? (int)(blockIdx.x % dm.nob) : 0;    // neighbouring workgroups: the same input tile, another output block
+    c16_item(dm, dm.nob > 1 ? blockIdx.x / dm.nob : blockIdx.x, b, ty0, tx0, d0, d1);      // (dm.tiles_x counts 30-column tiles here)
     tx0 = (tx0 / TW) * B3_TW;
     ty0 = (ty0 / TH) * B3_TH;
     const size_t plane = (size_t)dm.H * dm.W;
-    const float *inb = in + (size_t)b * dm.D * plane * CI;
-    float *outb = out + (size_t)b * dm.D * plane * CO;
+    const float *inb = in + ((size_t)b * dm.D * plane * dm.ip4 + dm.io4) * 4;
+    float *outb = out + ((size_t)b * dm.D * plane * dm.op4 + dm.oo4 + 4 * ob) * 4;
+    wt += (long long)ob * 16 * s_n;
     // weights: A operand of slice s, tap column kw: rows = output channel n, K = (tap row 2s + t, input channels 8o..8o+7)
     Bf3 wr[5][3];
 #pragma unroll
@@ -501,11 +508,11 @@ __global__ __launch_bounds__(256, B3_TWO ? 2 : 1) void conv3d_c16_fwd_bf3_kernel
     for (int i = 0; i < B3_NLD; ++i) {
         const int idx = tid + i * 256, cell = idx >> 2, qq = idx & 3;
         const int yy = ty0 - 1 + cell / B3_XW, xx = tx0 - 1 + cell % B3_XW;
-        ofs[i] = (idx < B3_CELLS * 4 && yy >= 0 && yy < dm.H && xx >= 0 && xx < dm.W) ? (yy * dm.W + xx) * 4 + qq : -1;
+        ofs[i] = (idx < B3_CELLS * 4 && yy >= 0 && yy < dm.H && xx >= 0 && xx < dm.W) ? (yy * dm.W + xx) * dm.ip4 + qq : -1;
     }
     auto fetch = [&](int P) {
         const bool inr = P >= 0 && P < dm.D;
-        const float4 *b4 = reinterpret_cast<const float4 *>(inb) + (size_t)(inr ? P : 0) * plane * 4;
+        const float4 *b4 = reinterpret_cast<const float4 *>(inb) + (size_t)(inr ? P : 0) * plane * dm.ip4;
 #pragma unroll
         for (int i = 0; i < B3_NLD; ++i) {
             if (inr && ofs[i] >= 0) {
@@ -608,9 +615,19 @@ __global__ __launch_bounds__(256, B3_TWO ? 2 : 1) void conv3d_c16_fwd_bf3_kernel
             const int yy = ty0 + row;
             if (yy < dm.H) {
                 const int x0 = tx0 + n - 1, x1 = tx0 + 15 + n;
-                float4 *o4 = reinterpret_cast<float4 *>(outb) + ((size_t)d * plane + (size_t)yy * dm.W) * 4 + q;
-                if (n >= 1 && x0 < dm.W) o4[(size_t)x0 * 4] = make_float4(o0.x, o0.y, o0.z, o0.w);
-                if (n <= 14 && x1 < dm.W) o4[(size_t)x1 * 4] = make_float4(o1.x, o1.y, o1.z, o1.w);
+                float4 *o4 = reinterpret_cast<float4 *>(outb) + ((size_t)d * plane + (size_t)yy * dm.W) * dm.op4 + q;
+                if (n >= 1 && x0 < dm.W) {
+                    float4 *p_ = o4 + (size_t)x0 * dm.op4;
+                    float4 v_ = make_float4(o0.x, o0.y, o0.z, o0.w);
+                    if (dm.acc) { const float4 a_ = *p_; v_.x += a_.x; v_.y += a_.y; v_.z += a_.z; v_.w += a_.w; }
+                    *p_ = v_;
+                }
+                if (n <= 14 && x1 < dm.W) {
+                    float4 *p_ = o4 + (size_t)x1 * dm.op4;
+                    float4 v_ = make_float4(o1.x, o1.y, o1.z, o1.w);
+                    if (dm.acc) { const float4 a_ = *p_; v_.x += a_.x; v_.y += a_.y; v_.z += a_.z; v_.w += a_.w; }
+                    *p_ = v_;
+                }
             }
         }
         __syncthreads();
@@ -642,11 +659,17 @@ __global__ __launch_bounds__(256, 2) void conv3d_c16_bwd_weight_bf3_kernel(const
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ch = lane & 15, q = lane >> 4;      // operand row / column (a channel), K octet: voxels 8q .. 8q+7 of the tile row
     int b, ty0, tx0, d0, d1;
-    c16_item(dm, blockIdx.x, b, ty0, tx0, d0, d1);
+    // md_conv3d_cb_bwd_weight: every (output block, input block) pair in one launch -- pair blockIdx % nob (nob pairs, ip4 / 4 input
+    // blocks), its partials behind those of the pairs before it
+    const int pair = dm.nob > 1 ? (int)(blockIdx.x % dm.nob) : 0, item = dm.nob > 1 ? (int)(blockIdx.x / dm.nob) : (int)blockIdx.x;
+    const int nib = dm.ip4 / 4, pib = dm.nob > 1 ? pair % nib : 0, pob = dm.nob > 1 ? pair / nib : 0;
+    c16_item(dm, item, b, ty0, tx0, d0, d1);
     ty0 = (ty0 / TH) * W3_TH;
     const size_t plane = (size_t)dm.H * dm.W;
-    const float *xb = x + (size_t)b * dm.D * plane * CI;
-    const float *gyb = gy + (size_t)b * dm.D * plane * CO;
+    const float *xb = x + ((size_t)b * dm.D * plane * dm.ip4 + dm.io4 + 4 * pib) * 4;      // (ip4 / io4: the x block, op4 / oo4: the gy block -- C16Dims)
+    const float *gyb = gy + ((size_t)b * dm.D * plane * dm.op4 + dm.oo4 + 4 * pob) * 4;
+    partial += (size_t)pair * (gridDim.x / max(dm.nob, 1)) * NTAP * CI * CO;
+    const int gyp = dm.op4 * 4;
     // staging of x: cells (rows ty0-1 .., columns tx0-1 ..) x channel quarters through registers; zeros outside the volume
     int ofs[W3_NLD];
     float4 pre[W3_NLD];
@@ -654,11 +677,11 @@ __global__ __launch_bounds__(256, 2) void conv3d_c16_bwd_weight_bf3_kernel(const
     for (int i = 0; i < W3_NLD; ++i) {
         const int idx = tid + i * 256, cell = idx >> 2, qq = idx & 3;
         const int yy = ty0 - 1 + cell / W3_XWC, xx = tx0 - 1 + cell % W3_XWC;
-        ofs[i] = (idx < W3_XH * W3_XWC * 4 && yy >= 0 && yy < dm.H && xx >= 0 && xx < dm.W) ? (yy * dm.W + xx) * 4 + qq : -1;
+        ofs[i] = (idx < W3_XH * W3_XWC * 4 && yy >= 0 && yy < dm.H && xx >= 0 && xx < dm.W) ? (yy * dm.W + xx) * dm.ip4 + qq : -1;
     }
     auto fetch = [&](int P) {
         const bool inr = P >= 0 && P < dm.D;
-        const float4 *b4 = reinterpret_cast<const float4 *>(xb) + (size_t)(inr ? P : 0) * plane * 4;
+        const float4 *b4 = reinterpret_cast<const float4 *>(xb) + (size_t)(inr ? P : 0) * plane * dm.ip4;
 #pragma unroll
         for (int i = 0; i < W3_NLD; ++i) {
             if (inr && ofs[i] >= 0) {
@@ -702,7 +725,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_c16_bwd_weight_bf3_kernel(const
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int xx = tx0 + 8 * q + j;
-            g8[j] = (yy < dm.H && xx < dm.W) ? __builtin_nontemporal_load(gyb + ((size_t)d * plane + (size_t)yy * dm.W + xx) * CO + ch) : 0.f;
+            g8[j] = (yy < dm.H && xx < dm.W) ? __builtin_nontemporal_load(gyb + ((size_t)d * plane + (size_t)yy * dm.W + xx) * gyp + ch) : 0.f;
         }
         stash(d + 1);
         __syncthreads();
@@ -767,7 +790,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_c16_bwd_weight_bf3_kernel(const
     }
     __syncthreads();
     if (wave == 0) {
-        f32x4 *out = reinterpret_cast<f32x4 *>(partial) + (size_t)blockIdx.x * NTAP * 64;
+        f32x4 *out = reinterpret_cast<f32x4 *>(partial) + (size_t)item * NTAP * 64;
 #pragma unroll
         for (int k = 0; k < NTAP; ++k) out[k * 64 + lane] = acc[k] + red[k * 64 + lane];
     }
@@ -778,6 +801,7 @@ int c16_dims(const char *fn, int B, int Ci, int Co, int D, int H, int W, C16Dims
     MD_REQUIRE(Ci == CI && Co == CO, "%s: %d -> %d channels unsupported (16 -> 16 only)", fn, Ci, Co);
     MD_REQUIRE((long long)D * H * W * CI < (1ll << 31), "%s: one sample must stay below 2^31 elements", fn);
     dm.B = B; dm.D = D; dm.H = H; dm.W = W;
+    dm.ip4 = 4; dm.io4 = 0; dm.op4 = 4; dm.oo4 = 0; dm.acc = 0; dm.nob = 1;
     dm.tiles_x = md_cdiv(W, TW);
     dm.tiles = dm.tiles_x * md_cdiv(H, TH);
     // two workgroups fit a CU (65 KB of LDS each): at least ~3 per CU in total for balance, >= 8 planes per slice
@@ -875,6 +899,82 @@ int md_conv3d_c16_bwd_weight(const float *x, int x_planar, const float *gy, floa
     hipLaunchKernelGGL(conv3d_c16_bwd_weight_finish_kernel, dim3(NTAP * 256 / 16), dim3(256), 0, s, partial, nwg, dw_stride_co,
                        dw_stride_ci, dw_stride_k, dwt);
     MD_CHECK_LAUNCH("md_conv3d_c16_bwd_weight(finish)");
+    return MD_OK;
+}
+
+// ---- Ci, Co multiples of 16: the regulariser's interior 3 x 3 x 3 layers (32 -> 32 ...) as sums over 16 x 16 channel blocks on the bf16 x 3
+// kernels above (C16Dims::ip4 ...): Co/16 x Ci/16 launches per direction, the second and later input blocks of an output block added in
+// the epilogue.  Channels-last volumes only.
+static int cb_check(const char *fn, int Ci, int Co) {
+    MD_REQUIRE(Ci >= 16 && Co >= 16 && Ci % 16 == 0 && Co % 16 == 0 && Ci <= 256 && Co <= 256, "%s: Ci and Co must be multiples of 16 (<= 256), got %d -> %d", fn, Ci, Co);
+    return MD_OK;
+}
+
+static int cb_launch_fwd(const char *fn, const float *in, int Cin, const float *wt, long long s_n, long long s_m, long long s_k, int mirror,
+                         float *out, int Cout, int B, int D, int H, int W, md_stream_t stream) {
+    MD_REQUIRE(in && wt && out, "%s: null tensor argument", fn);
+    MD_REQUIRE(((uintptr_t)in % 16) == 0 && ((uintptr_t)out % 16) == 0, "%s: volumes must be 16-byte aligned", fn);
+    C16Dims dm;
+    if (int rc = c16_dims(fn, B, CI, CO, D, H, W, dm)) return rc;
+    dm.tiles_x = md_cdiv(W, B3_TW);
+    dm.tiles = dm.tiles_x * md_cdiv(H, B3_TH);
+    // one launch per INPUT block, covering every output block (the workgroups of a tile's output blocks are neighbours: the tile's
+    // input planes come from L2 after the first); the later input blocks add to what the earlier ones stored
+    const int nob = Cout / 16;
+    const dim3 grid(B * dm.tiles * dm.dslices * nob), block(256);
+    for (int ib = 0; ib < Cin / 16; ++ib) {
+        C16Dims d = dm;
+        d.ip4 = Cin / 4; d.io4 = ib * 4; d.op4 = Cout / 4; d.oo4 = 0; d.acc = ib > 0; d.nob = nob;
+        const float *wp = wt + (long long)ib * 16 * s_m;
+        MD_LAUNCH_TIMED(fn, conv3d_c16_fwd_bf3_kernel, grid, block, 0, (hipStream_t)stream, in, wp, s_n, s_m, s_k, mirror, out, d);
+        MD_CHECK_LAUNCH(fn);
+    }
+    return MD_OK;
+}
+
+int md_conv3d_cb_fwd(const float *x, const float *wt, long long w_stride_co, long long w_stride_ci, long long w_stride_k, float *y,
+                     int B, int Ci, int Co, int D, int H, int W, md_stream_t stream) {
+    if (int rc = cb_check("md_conv3d_cb_fwd", Ci, Co)) return rc;
+    return cb_launch_fwd("md_conv3d_cb_fwd", x, Ci, wt, w_stride_co, w_stride_ci, w_stride_k, 0, y, Co, B, D, H, W, stream);
+}
+
+int md_conv3d_cb_bwd_data(const float *gy, const float *wt, long long w_stride_co, long long w_stride_ci, long long w_stride_k,
+                          float *dx, int B, int Ci, int Co, int D, int H, int W, md_stream_t stream) {
+    if (int rc = cb_check("md_conv3d_cb_bwd_data", Ci, Co)) return rc;
+    // the same kernel with the taps mirrored and the weight's channel roles swapped: its "output" channels are the layer's inputs
+    return cb_launch_fwd("md_conv3d_cb_bwd_data", gy, Co, wt, w_stride_ci, w_stride_co, w_stride_k, 1, dx, Ci, B, D, H, W, stream);
+}
+
+size_t md_conv3d_cb_bwd_weight_ws_bytes(int B, int Ci, int Co, int D, int H, int W) {
+    if (Ci < 16 || Co < 16 || Ci % 16 || Co % 16) return 0;
+    return md_conv3d_c16_bwd_weight_ws_bytes(B, D, H, W) * (size_t)(Ci / 16) * (size_t)(Co / 16);
+}
+
+int md_conv3d_cb_bwd_weight(const float *x, const float *gy, float *dwt, long long dw_stride_co, long long dw_stride_ci,
+                            long long dw_stride_k, void *ws, size_t ws_bytes, int B, int Ci, int Co, int D, int H, int W,
+                            md_stream_t stream) {
+    if (int rc = cb_check("md_conv3d_cb_bwd_weight", Ci, Co)) return rc;
+    MD_REQUIRE(x && gy && dwt && ws, "md_conv3d_cb_bwd_weight: null tensor argument");
+    MD_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)gy % 16) == 0 && ((uintptr_t)ws % 16) == 0, "md_conv3d_cb_bwd_weight: x, gy and ws must be 16-byte aligned");
+    C16Dims dm;
+    if (int rc = c16_dims("md_conv3d_cb_bwd_weight", B, CI, CO, D, H, W, dm)) return rc;
+    c16_dims_w3(dm, H);
+    const int nwg = B * dm.tiles * dm.dslices, nib = Ci / 16, npair = nib * (Co / 16);
+    const size_t per_pair = (size_t)nwg * NTAP * CI * CO;
+    MD_REQUIRE(ws_bytes >= per_pair * npair * sizeof(float), "md_conv3d_cb_bwd_weight: workspace too small (%zu bytes)", ws_bytes);
+    hipStream_t s = (hipStream_t)stream;
+    float *partial = (float *)ws;
+    // every (output block, input block) pair in ONE launch (a tile's pairs are neighbouring workgroups), then a finish per pair
+    C16Dims d = dm;
+    d.ip4 = Ci / 4; d.io4 = 0; d.op4 = Co / 4; d.oo4 = 0; d.nob = npair;
+    MD_LAUNCH_TIMED("md_conv3d_cb_bwd_weight", conv3d_c16_bwd_weight_bf3_kernel, dim3(nwg * npair), dim3(256), 0, s, x, gy, partial, d);
+    MD_CHECK_LAUNCH("md_conv3d_cb_bwd_weight");
+    for (int pair = 0; pair < npair; ++pair) {
+        const int ib = pair % nib, ob = pair / nib;
+        hipLaunchKernelGGL(conv3d_c16_bwd_weight_finish_kernel, dim3(NTAP * 256 / 16), dim3(256), 0, s, partial + per_pair * pair, nwg, dw_stride_co,
+                           dw_stride_ci, dw_stride_k, dwt + (long long)ob * 16 * dw_stride_co + (long long)ib * 16 * dw_stride_ci);
+        MD_CHECK_LAUNCH("md_conv3d_cb_bwd_weight(finish)");
+    }
     return MD_OK;
 }
 

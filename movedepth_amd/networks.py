@@ -311,8 +311,20 @@ class ConvBnReLU3D(nn.Module):
         self.conv = nn.Conv3d(cin, cout, kernel_size, stride=stride, padding=pad, bias=False)
         self.bn = nn.BatchNorm3d(cout)
 
+    # True (reg3d.conv2, set by the trainer: --hip_conv2): the convolution as 16 x 16 channel blocks on the 16 -> 16 layer's bf16 x 3
+    # kernels (ops.conv3d_cb) where they apply -- fp32 channels-last activations outside autocast, 3 x 3 x 3, stride 1, padding 1
+    hip_cb = False
+
+    def _conv(self, x):
+        c = self.conv
+        if self.hip_cb and x.is_cuda and not torch.is_autocast_enabled() and c.stride == (1, 1, 1) and c.padding == (1, 1, 1) and \
+                c.dilation == (1, 1, 1) and c.groups == 1 and c.bias is None and ops.conv3d_cb_supported(x, c.weight) and \
+                x.is_contiguous(memory_format=torch.channels_last_3d):
+            return ops.conv3d_cb(x, c.weight)
+        return c(x)
+
     def forward(self, x):
-        y = self.bn(self.conv(x))
+        y = self.bn(self._conv(x))
         # the fused modules include the ReLU
         return y if (isinstance(self.bn, FusedBNReLU3d) or getattr(self.bn, "relu", False)) else F.relu(y, inplace=True)
 

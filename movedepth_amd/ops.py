@@ -913,6 +913,56 @@ def conv3d_16(x, weight, lib_fwd_dgrad=False):
     return _Conv3d16.apply(x.float(), weight.float(), lib_fwd_dgrad)
 
 
+# --------------------------------------------------------------------------- reg3d's interior layers (Ci, Co multiples of 16)
+class _Conv3dCB(torch.autograd.Function):
+    """3 x 3 x 3, stride 1, padding 1, no bias, Ci and Co multiples of 16, on the bf16 x 3 kernels of csrc/conv3d_c16.hip as sums
+    over 16 x 16 channel blocks (md_conv3d_cb_*).  Channels_last_3d in and out."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        x = x.contiguous(memory_format=torch.channels_last_3d)
+        ctx.save_for_backward(x, weight)
+        B, C, D, H, W = x.shape
+        y = torch.empty((B, weight.shape[0], D, H, W), device=x.device, dtype=torch.float32, memory_format=torch.channels_last_3d)
+        _timed_call("md_conv3d_cb_fwd", _p(x), _p(weight), *_c16_weight_strides(weight), _p(y), B, C, weight.shape[0], D, H, W, _stream())
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        B, C, D, H, W = x.shape
+        gy = gy.float().contiguous(memory_format=torch.channels_last_3d)
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x, memory_format=torch.channels_last_3d)
+            _timed_call("md_conv3d_cb_bwd_data", _p(gy), _p(weight), *_c16_weight_strides(weight), _p(dx), B, C, weight.shape[0], D, H, W,
+                        _stream())
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(weight)  # keeps the weight's strides
+            nbytes = _lib.load().md_conv3d_cb_bwd_weight_ws_bytes(B, C, weight.shape[0], D, H, W)
+            ws = _ws(nbytes, x.device)
+            _timed_call("md_conv3d_cb_bwd_weight", _p(x), _p(gy), _p(dw), *_c16_weight_strides(dw), _p(ws), int(nbytes), B, C,
+                        weight.shape[0], D, H, W, _stream())
+        return dx, dw
+
+
+def conv3d_cb_supported(x, weight):
+    return (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and weight.dim() == 5
+            and tuple(weight.shape[2:]) == (3, 3, 3) and weight.shape[0] % 16 == 0 and weight.shape[1] % 16 == 0
+            and weight.shape[0] <= 256 and weight.shape[1] <= 256 and x.shape[1] == weight.shape[1])
+
+
+def conv3d_cb(x, weight):
+    """nn.Conv3d(Ci, Co, 3, stride=1, padding=1, bias=False) with Ci, Co multiples of 16 -- reg3d's conv2 / conv4 / conv6 (reference
+    networks/resnet_encoder.py:235-245).  x (B,Ci,D,H,W) fp32 on the GPU (read as channels_last_3d), weight (Co,Ci,3,3,3) in either memory
+    format; returns a channels_last_3d (B,Co,D,H,W) tensor.  Products on the bf16 matrix pipe with three-piece operands: fp32 results to
+    ~4e-7 relative."""
+    if not conv3d_cb_supported(x, weight):
+        raise _lib.MovedepthHipError("conv3d_cb: needs fp32 GPU tensors, a (Co,Ci,3,3,3) weight with Ci, Co multiples of 16 (<= 256), got %s %s %s"
+                                     % (x.device, tuple(x.shape), tuple(weight.shape)))
+    return _Conv3dCB.apply(x, weight)
+
+
 # --------------------------------------------------------------------------- BatchNorm + ReLU (+ residual), 16 channels
 class _BnRelu3d(torch.autograd.Function):
     """Training-mode BatchNorm3d + ReLU (+ residual add) over a channels_last_3d (B,16,D,H,W) tensor in 3 + 5 passes

@@ -86,6 +86,9 @@ class MonodepthOptions:
                        help="run the 3-D regulariser in channels_last_3d and write the cost volume as (B,D,h,w,G)")
         p.add_argument("--hip_prob_conv", type=int, default=1,
                        help="the 3-D regulariser's last (C->1) convolution on the hand-written kernels (0: library)")
+        p.add_argument("--hip_conv2", type=int, default=1,
+                       help="reg3d.conv2 (32 -> 32 at half resolution) as 16 x 16 channel blocks on the hand-written bf16 x 3 kernels "
+                            "(fp32 steps; 0: the library convolution)")
         p.add_argument("--hip_conv0", default="all", choices=["all", "wgrad", "none"],
                        help="the 3-D regulariser's first convolution on the MFMA kernels: all three directions, the "
                             "weight gradient only, or none (library)")

@@ -1046,6 +1046,61 @@ def test_conv0_vs_oracle(ops, oracle_lib, shape, planar):
     assert_close(host(dw), exp_dw, what="d_weight")
 
 
+@pytest.mark.parametrize("weight_cl", [False, True])
+@pytest.mark.parametrize("chans,shape", [
+    ((32, 32), (2, 5, 9, 33)),     # ragged tiles, two blocks each way
+    ((48, 32), (1, 3, 6, 31)),     # three input blocks: two accumulating launches per output block
+    ((32, 64), (1, 4, 4, 40)),
+    ((16, 32), (2, 2, 5, 17)),
+    ((64, 64), (1, 9, 7, 12)),
+])
+def test_conv3d_channel_blocks_vs_oracle(ops, oracle_lib, chans, shape, weight_cl):
+    """reg3d's interior stride-1 layers (networks/resnet_encoder.py:235-245: ConvBnReLU3D(32,32), (64,64), (128,128)) as sums over
+    16 x 16 channel blocks on the 16 -> 16 layer's bf16 x 3 kernels (md_conv3d_cb_*: record pitch / block offset / accumulate in the
+    epilogue): forward, data gradient and weight gradient against the oracle's direct convolution."""
+    rng = np.random.default_rng(41)
+    Ci, Co = chans
+    B, D, H, W = shape
+    x = rng.standard_normal((B, Ci, D, H, W)).astype(np.float32)
+    wt = (rng.standard_normal((Co, Ci, 3, 3, 3)) * 0.1).astype(np.float32)
+    gy = rng.standard_normal((B, Co, D, H, W)).astype(np.float32)
+    exp_y, exp_dx, exp_dw = oracle_lib.conv3d(x, wt, gy)
+    xt = _cl3d(dev(x)).requires_grad_(True)
+    wtt = dev(wt)
+    if weight_cl:
+        wtt = wtt.contiguous(memory_format=torch.channels_last_3d)
+    wtt.requires_grad_(True)
+    y = ops.conv3d_cb(xt, wtt)
+    assert y.is_contiguous(memory_format=torch.channels_last_3d)
+    assert_close(host(y), exp_y, what="y")
+    dx, dw = torch.autograd.grad(y, (xt, wtt), _cl3d(dev(gy)))
+    assert dw.stride() == wtt.stride()
+    assert_close(host(dx), exp_dx, what="d_x")
+    assert_close(host(dw), exp_dw, what="d_weight")
+
+
+def test_conv3d_channel_blocks_layer_size_vs_library(ops):
+    """reg3d.conv2 at BASELINE config 2 (6 x 32 x 48 x 24 x 80): all three directions against the library's fp32 convolution, the
+    forward / data-gradient adjoint identity, and the weight gradient bit-reproducible."""
+    torch.manual_seed(8)
+    B, C, D, H, W = 6, 32, 48, 24, 80
+    x = _cl3d(torch.randn(B, C, D, H, W, device="cuda")).requires_grad_(True)
+    w = (torch.randn(C, C, 3, 3, 3, device="cuda") * 0.05).requires_grad_(True)
+    gy = _cl3d(torch.randn(B, C, D, H, W, device="cuda"))
+    y = ops.conv3d_cb(x, w)
+    dx, dw = torch.autograd.grad(y, (x, w), gy, retain_graph=True)
+    y_ref = torch.nn.functional.conv3d(x.detach(), w.detach(), padding=1)
+    dx_ref, dw_ref, _ = torch.ops.aten.convolution_backward(gy, x.detach(), w.detach(), None, [1] * 3, [1] * 3, [1] * 3, False,
+                                                            [0] * 3, 1, [True, True, False])
+    assert_close(host(y), host(y_ref), what="y vs library")
+    assert_close(host(dx), host(dx_ref), what="d_x vs library")
+    assert_close(host(dw), host(dw_ref), what="d_weight vs library")
+    lhs, rhs = (y.detach().double() * gy.double()).sum().item(), (x.detach().double() * dx.double()).sum().item()
+    assert abs(lhs - rhs) <= 1e-5 * max(abs(lhs), abs(rhs), 1.0), "forward and data gradient are not adjoint: %r %r" % (lhs, rhs)
+    dw2 = torch.autograd.grad(y, w, gy)[0]
+    assert torch.equal(dw, dw2), "the weight gradient must be bit-reproducible"
+
+
 def test_conv0_full_size_vs_library(ops):
     """BASELINE config 2 size: all three directions against the library; weight gradient bit-reproducible and linear
     in gy; forward / data gradient adjoint to each other (<y, gy> == <x, dx>, a size-independent property)."""
