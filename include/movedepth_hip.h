@@ -290,7 +290,7 @@ int md_conv3d_c16_bwd_weight(const float *x, int x_planar, const float *gy, floa
                              long long dw_stride_ci, long long dw_stride_k, void *ws, size_t ws_bytes, int B, int Ci, int Co,
                              int D, int H, int W, md_stream_t stream);
 
-/* ---- reg3d's interior 3x3x3 layers with Ci, Co multiples of 16 (`conv2`, `conv4`, `conv6` of networks/resnet_encoder.py:235-245:
+/* ---- reg3d's interior 3x3x3 layers with Ci, Co multiples of 16 (`conv2`, `conv4`, `conv6` of networks/resnet_encoder.py:233-239, applied :260-262:
  * ConvBnReLU3D(32, 32), (64, 64), (128, 128), stride 1, padding 1, bias=False), as sums over 16 x 16 channel blocks on the
  * bf16 x 3 kernels of the 16 -> 16 layer: forward / data gradient one launch per input block covering every output block, the later
  * input blocks added in the kernel's epilogue; weight gradient one launch for all block pairs.  Channels-last volumes [B,D,H,W,C] only, 16-byte aligned; weights addressed as above (any strides);

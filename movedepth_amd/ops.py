@@ -954,7 +954,7 @@ def conv3d_cb_supported(x, weight):
 
 def conv3d_cb(x, weight):
     """nn.Conv3d(Ci, Co, 3, stride=1, padding=1, bias=False) with Ci, Co multiples of 16 -- reg3d's conv2 / conv4 / conv6 (reference
-    networks/resnet_encoder.py:235-245).  x (B,Ci,D,H,W) fp32 on the GPU (read as channels_last_3d), weight (Co,Ci,3,3,3) in either memory
+    networks/resnet_encoder.py:233-239, applied :260-262).  x (B,Ci,D,H,W) fp32 on the GPU (read as channels_last_3d), weight (Co,Ci,3,3,3) in either memory
     format; returns a channels_last_3d (B,Co,D,H,W) tensor.  Products on the bf16 matrix pipe with three-piece operands: fp32 results to
     ~4e-7 relative."""
     if not conv3d_cb_supported(x, weight):

@@ -1055,7 +1055,7 @@ def test_conv0_vs_oracle(ops, oracle_lib, shape, planar):
     ((64, 64), (1, 9, 7, 12)),
 ])
 def test_conv3d_channel_blocks_vs_oracle(ops, oracle_lib, chans, shape, weight_cl):
-    """reg3d's interior stride-1 layers (networks/resnet_encoder.py:235-245: ConvBnReLU3D(32,32), (64,64), (128,128)) as sums over
+    """reg3d's interior stride-1 layers (networks/resnet_encoder.py:233-239, applied :260-262: ConvBnReLU3D(32,32), (64,64), (128,128)) as sums over
     16 x 16 channel blocks on the 16 -> 16 layer's bf16 x 3 kernels (md_conv3d_cb_*: record pitch / block offset / accumulate in the
     epilogue): forward, data gradient and weight gradient against the oracle's direct convolution."""
     rng = np.random.default_rng(41)
