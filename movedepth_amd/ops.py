@@ -858,6 +858,21 @@ def _is_planar(t):
     return t.is_contiguous() and not t.is_contiguous(memory_format=torch.channels_last_3d)
 
 
+def _w_for_forward(w):
+    """The weight with its OUTPUT-channel stride 1 (storage order ci, tap, co).  A workgroup of the bf16 x 3 kernels gathers its 120 weights
+    per lane straight from memory, lane = output channel (forward) or input channel (data gradient): with the lane index strided by
+    Ci * 27 floats that prologue cost the forward 28 us of 387 at 16 -> 16 and 80 of 318 at 32 -> 32 (tools/r05/cb_wlayout.py); a
+    transposed copy of the 27-110 KB tensor is one small kernel."""
+    if w.stride(0) == 1:
+        return w
+    return w.permute(1, 0, 2, 3, 4).contiguous(memory_format=torch.channels_last_3d).permute(1, 0, 2, 3, 4)
+
+
+def _w_for_dgrad(w):
+    """... and with its INPUT-channel stride 1 (channels_last_3d storage: what a channels-last module holds anyway)."""
+    return w if w.stride(1) == 1 else w.contiguous(memory_format=torch.channels_last_3d)
+
+
 class _Conv3d16(torch.autograd.Function):
     """reg3d.conv0's convolution on the MFMA kernels of csrc/conv3d_c16.hip.  x may be planar (contiguous
     [B,16,D,H,W], what md_costvol_fwd writes fastest) or channels_last_3d; y is channels_last_3d; dx has x's layout.
@@ -877,7 +892,8 @@ class _Conv3d16(torch.autograd.Function):
         B, C, D, H, W = x.shape
         y = torch.empty((B, weight.shape[0], D, H, W), device=x.device, dtype=torch.float32,
                         memory_format=torch.channels_last_3d)
-        _timed_call("md_conv3d_c16_fwd", _p(x), int(planar), _p(weight), *_c16_weight_strides(weight), _p(y), B, C,
+        wf = _w_for_forward(weight)
+        _timed_call("md_conv3d_c16_fwd", _p(x), int(planar), _p(wf), *_c16_weight_strides(wf), _p(y), B, C,
                     weight.shape[0], D, H, W, _stream())
         return y
 
@@ -892,7 +908,8 @@ class _Conv3d16(torch.autograd.Function):
                 dx = torch.ops.aten.convolution_backward(gy, x, weight, None, *_CONV_ARGS, [True, False, False])[0]
             else:
                 dx = torch.empty_like(x, memory_format=torch.contiguous_format if ctx.planar else torch.channels_last_3d)
-                _timed_call("md_conv3d_c16_bwd_data", _p(gy), _p(weight), *_c16_weight_strides(weight), _p(dx),
+                wd = _w_for_dgrad(weight)
+                _timed_call("md_conv3d_c16_bwd_data", _p(gy), _p(wd), *_c16_weight_strides(wd), _p(dx),
                             int(ctx.planar), B, C, weight.shape[0], D, H, W, _stream())
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(weight)  # keeps the weight's strides
@@ -924,7 +941,8 @@ class _Conv3dCB(torch.autograd.Function):
         ctx.save_for_backward(x, weight)
         B, C, D, H, W = x.shape
         y = torch.empty((B, weight.shape[0], D, H, W), device=x.device, dtype=torch.float32, memory_format=torch.channels_last_3d)
-        _timed_call("md_conv3d_cb_fwd", _p(x), _p(weight), *_c16_weight_strides(weight), _p(y), B, C, weight.shape[0], D, H, W, _stream())
+        wf = _w_for_forward(weight)
+        _timed_call("md_conv3d_cb_fwd", _p(x), _p(wf), *_c16_weight_strides(wf), _p(y), B, C, weight.shape[0], D, H, W, _stream())
         return y
 
     @staticmethod
@@ -935,7 +953,8 @@ class _Conv3dCB(torch.autograd.Function):
         dx = dw = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x, memory_format=torch.channels_last_3d)
-            _timed_call("md_conv3d_cb_bwd_data", _p(gy), _p(weight), *_c16_weight_strides(weight), _p(dx), B, C, weight.shape[0], D, H, W,
+            wd = _w_for_dgrad(weight)
+            _timed_call("md_conv3d_cb_bwd_data", _p(gy), _p(wd), *_c16_weight_strides(wd), _p(dx), B, C, weight.shape[0], D, H, W,
                         _stream())
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(weight)  # keeps the weight's strides
