@@ -367,7 +367,8 @@ def main():
 
     for _ in range(a.warmup):
         trainer.train_step(dict(inputs))
-    CONV_KERNELS = ["md_conv3d_c16_fwd", "md_conv3d_c16_bwd_data", "md_conv3d_c16_bwd_weight", "md_conv3d_c1_fwd",
+    CB_KERNELS = ["md_conv3d_cb_fwd", "md_conv3d_cb_bwd_data", "md_conv3d_cb_bwd_weight"]   # reg3d.conv2 (32 -> 32) as 16 x 16 channel blocks
+    CONV_KERNELS = CB_KERNELS + ["md_conv3d_c16_fwd", "md_conv3d_c16_bwd_data", "md_conv3d_c16_bwd_weight", "md_conv3d_c1_fwd",
                     "md_conv3d_c1_bwd_data", "md_conv3d_c1_bwd_weight"]
     sfx = {"none": "", "bf16": "_bf16", "fp16": "_f16"}[opt.amp]
     # plane-sweep kernels: HIP events recorded inside the library directly around the kernel launch, on the launch stream
@@ -487,17 +488,33 @@ def main():
         }
         # the 3-D regulariser's first / last convolutions (hand-off either side of it), same live HIP-event timing (avg_us = the
         # kernel's own dispatch, as rocprofv3 reports it; entry_point_avg_us = events recorded from Python around the whole call):
-        # 16->16 is MFMA-bound (2*27*16*16 flop per voxel against the 157.3 TF/s fp32 MFMA peak), 16->1 is HBM-bound
+        # 16->16 / 32->32 are MFMA-bound (2*27*Ci*Co flop per voxel; peak: mfma_peak below), 16->1 is HBM-bound
         # (the 16-channel volume read or written once plus the 1-channel one)
         vox = opt.batch_size * opt.num_depth_bins * h * w
         conv = {}
+        # the 16 -> 16 / 32 -> 32 kernels multiply on the bf16 matrix pipe with three-piece operands (six bf16 products per fp32 product):
+        # their bound is the dense bf16 peak / 6 in fp32-equivalent flop (MD_C16_BF3=0 / MD_C16_BF3_WGRAD=0: the fp32 MFMA kernels, 157.3)
+        BF16_PEAK_TF = 2500.0
+
+        def mfma_peak(name):
+            off = os.environ.get("MD_C16_BF3_WGRAD" if name.endswith("weight") else "MD_C16_BF3", "1") == "0"
+            return (157.3, "fp32 MFMA peak") if (off and "_cb_" not in name) else (BF16_PEAK_TF / 6, "dense bf16 MFMA peak / 6 (bf16 x 3 operands: six products per fp32 product)")
+
         for name in CONV_KERNELS:
             kc = times.get(name)
             if not kc:
                 continue
             e = {"avg_us": kc["avg_us"], "launches_timed": kc["launches"], "entry_point_avg_us": entry_us.get(name)}
-            if "c16" in name:
-                e["bound"], e["achieved"], e["peak"], e["unit"] = "mfma", 2 * 27 * 16 * 16 * vox / kc["avg_us"] * 1e-6, 157.3, "TFLOP/s"
+            if "_cb_" in name:
+                # 32 -> 32 at half resolution: avg_us is ONE dispatch (forward / data gradient: one per input block = half the layer's
+                # 2 * 27 * 32 * 32 flop per voxel each; weight gradient: all of it), entry_point_avg_us the whole call
+                per = 2 * 27 * 32 * 32 * (vox / 8) * (1.0 if name.endswith("weight") else 0.5)
+                e["bound"], e["achieved"], e["unit"] = "mfma", per / kc["avg_us"] * 1e-6, "TFLOP/s (fp32-equivalent)"
+                e["peak"], e["peak_note"] = mfma_peak(name)
+                e["shape"] = "reg3d.conv2: %d x 32 x %d x %d x %d" % (opt.batch_size, opt.num_depth_bins // 2, h // 2, w // 2)
+            elif "c16" in name:
+                e["bound"], e["achieved"], e["unit"] = "mfma", 2 * 27 * 16 * 16 * vox / kc["avg_us"] * 1e-6, "TFLOP/s (fp32-equivalent)"
+                e["peak"], e["peak_note"] = mfma_peak(name)
             else:
                 e["bound"], e["achieved"], e["peak"], e["unit"] = "hbm", 4 * vox * (opt.reg3d_c + 1) / kc["avg_us"] * 1e-3, HBM_PEAK_GBS, "GB/s"
             e["frac"] = e["achieved"] / e["peak"]

@@ -1196,6 +1196,35 @@ def test_reg3d_conv0_paths_agree(ops, vol_layout):
 
 
 
+def test_reg3d_conv2_paths_agree(ops):
+    """reg3d with its 32 -> 32 layer (conv2) on the channel-block kernels (ConvBnReLU3D.hip_cb, the trainer's --hip_conv2) and on the
+    library: same logits and gradients, as test_reg3d_conv0_paths_agree; and the hand-written entry points did run."""
+    from movedepth_amd import networks
+    torch.manual_seed(5)
+    net = networks.reg3d(16, 16, 3).cuda().to(memory_format=torch.channels_last_3d)
+    assert net.conv2.conv.in_channels == 32 and net.conv2.conv.out_channels == 32
+    B, D, G, h, w = 2, 16, 16, 24, 32
+    vol = torch.randn(B, D, h, w, G, device="cuda").permute(0, 1, 4, 2, 3)
+    runs = []
+    for on in (True, False):
+        net.conv2.hip_cb = on
+        if on:
+            ops.enable_kernel_timing(["md_conv3d_cb_fwd", "md_conv3d_cb_bwd_data", "md_conv3d_cb_bwd_weight"])
+        out, masks = _reg3d_run(net, vol)
+        if on:
+            t = ops.kernel_times_us()
+            ops.enable_kernel_timing([])
+            assert all(t.get(k, {}).get("launches", 0) >= 1 for k in ("md_conv3d_cb_fwd", "md_conv3d_cb_bwd_data", "md_conv3d_cb_bwd_weight")), t
+        runs.append((out, masks, host(net.conv2.conv.weight.grad)))
+        net.zero_grad(set_to_none=True)
+    (out, masks, dw2), (ref_out, ref_masks, ref_dw2) = runs
+    flips = sum(int((a != b).sum()) for a, b in zip(masks, ref_masks))
+    assert flips <= 3, "%d ReLU decisions differ between the two conv2 implementations" % flips
+    assert_close(out[0], ref_out[0], what="logits")
+    for a, b, what in zip(out[1:] + (dw2,), ref_out[1:] + (ref_dw2,), ("d_volume", "d_conv0_weight", "d_conv2_weight")):
+        assert_close(a, b, rtol=1e-4 if flips == 0 else 5e-3, what="%s (%d ReLU flips)" % (what, flips))
+
+
 # ------------------------------------------------------------------ pose parameters -> 4x4
 @pytest.mark.parametrize("invert", [False, True])
 def test_pose_matrix_golden(ops, invert):
