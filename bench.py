@@ -300,10 +300,13 @@ def main():
     ap.add_argument("--trainer_args", default="", help="extra movedepth_amd options, e.g. '--hip_prob_conv 0' for an A/B")
     ap.add_argument("--epoch", type=int, default=0, help="trainer.epoch during the run (> ztrans_start_epc: velocity-guided bins)")
     ap.add_argument("--watchdog_s", type=float, default=float(os.environ.get("MD_BENCH_WATCHDOG_S", "0")),
-                    help="abort with exit code 124 when the run has not finished after this many seconds (default: 1800 for --gpus > 1, "
+                    help="abort with exit code 124 when the run has not finished after this many seconds (default: 1800 + 60 per step for --gpus > 1, "
                          "where a rank that died or a collective that cannot complete leaves the others waiting; off for one GPU)")
     a = ap.parse_args()
-    start_watchdog(a.watchdog_s if a.watchdog_s > 0 else (1800.0 if (a.gpus > 1 or int(os.environ.get("WORLD_SIZE", "1")) > 1) else 0.0))
+    # default for N > 1: 30 minutes plus a generous per-step allowance (an 8-rank shared-GPU gloo run takes 22 s per step: a long
+    # --steps run must not be reported as a hang)
+    multi = a.gpus > 1 or int(os.environ.get("WORLD_SIZE", "1")) > 1
+    start_watchdog(a.watchdog_s if a.watchdog_s > 0 else ((1800.0 + 60.0 * (a.steps + a.warmup)) if multi else 0.0))
     # stdout carries exactly one JSON line.  The convolution libraries write diagnostics to file descriptor 1 from C++ (CK's
     # "GridwiseOp: Problemsize descriptor dimension check failure" under fp16 autocast): point fd 1 at stderr for the run and
     # keep the real stdout for the line.
@@ -444,6 +447,28 @@ def main():
             print(k_, " ".join("%.0f" % t for t in times.get(k_, {}).get("all_us", [])), file=sys.stderr)
     ops.enable_library_kernel_timing(False)
 
+    # What one step sends, per rank (the first real N-GPU run should diagnose itself): one more step, outside the
+    # timed region, with the counters of the two places a collective is issued from (dp.GradSync._reduce: gradient buckets;
+    # ops._group_all_reduce: the BatchNorm layers' 2C sums), gathered to rank 0.
+    collectives = None
+    if world > 1 and trainer.grad_sync is not None:
+        gs = trainer.grad_sync
+        c0, b0, n0, y0 = gs.reduce_calls, gs.reduce_bytes, ops.GROUP_ALL_REDUCE[0], ops.GROUP_ALL_REDUCE[1]
+        trainer.train_step(dict(inputs))
+        torch.cuda.synchronize()
+        mine = {"rank": rank, "bucket_all_reduces": gs.reduce_calls - c0, "bucket_bytes": gs.reduce_bytes - b0,
+                "batchnorm_all_reduces": ops.GROUP_ALL_REDUCE[0] - n0, "batchnorm_bytes": ops.GROUP_ALL_REDUCE[1] - y0}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
+        direct = trainer.direct_all_reduce is not None
+        collectives = {
+            "path": ("ncclAllReduce on the compute stream, one communicator for buckets and BatchNorm statistics (MD_DIRECT_RCCL=1)" if direct else
+                     "torch.distributed all_reduce on the process group's stream (%s), buckets async behind backward" % dist.get_backend()),
+            "per_step_per_rank": per_rank,
+            "identical_on_every_rank": all({k: v for k, v in r.items() if k != "rank"} == {k: v for k, v in per_rank[0].items() if k != "rank"}
+                                           for r in per_rank),
+            "grad_bucket_mb": opt.grad_bucket_mb, "buckets": len(gs.buckets), "sync_bn": bool(opt.sync_bn), "sync_bn_impl": opt.sync_bn_impl,
+        }
     if rank == 0:
         gb = opt.batch_size * world
         h, w = opt.height // 4, opt.width // 4
@@ -478,7 +503,7 @@ def main():
                                        {"none": "fp32", "bf16": "bf16 autocast", "fp16": "fp16 autocast"}[opt.amp],
                                        len(opt.matching_ids), ", velocity-guided bins" if a.epoch > opt.ztrans_start_epc else "",
                                        (" [" + a.trainer_args + "]") if a.trainer_args else ""),
-                       "global_batch": gb, "parallelism": "dp%d" % world, "final_loss": loss_val},
+                       "global_batch": gb, "parallelism": "dp%d" % world, "final_loss": loss_val, "collectives": collectives},
             "roofline": {"bound": "hbm", "kernel": "md_costvol_fwd%s (plane-sweep cost volume, fused schedule + group mean)" % sfx,
                          "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (ach / HBM_PEAK_GBS) if ach else None,
                          "traffic": traffic, "traffic_from_profile": traffic_profile, "algorithmic_bytes_per_launch": fbytes,
@@ -493,12 +518,11 @@ def main():
         vox = opt.batch_size * opt.num_depth_bins * h * w
         conv = {}
         # the 16 -> 16 / 32 -> 32 kernels multiply on the bf16 matrix pipe with three-piece operands (six bf16 products per fp32 product):
-        # their bound is the dense bf16 peak / 6 in fp32-equivalent flop (MD_C16_BF3=0 / MD_C16_BF3_WGRAD=0: the fp32 MFMA kernels, 157.3)
+        # their bound is the dense bf16 peak / 6 in fp32-equivalent flop
         BF16_PEAK_TF = 2500.0
 
-        def mfma_peak(name):
-            off = os.environ.get("MD_C16_BF3_WGRAD" if name.endswith("weight") else "MD_C16_BF3", "1") == "0"
-            return (157.3, "fp32 MFMA peak") if (off and "_cb_" not in name) else (BF16_PEAK_TF / 6, "dense bf16 MFMA peak / 6 (bf16 x 3 operands: six products per fp32 product)")
+        def mfma_peak(name):   # (a -DMD_C16_BF3=0 A/B build runs the fp32 MFMA kernels instead: peak 157.3)
+            return (BF16_PEAK_TF / 6, "dense bf16 MFMA peak / 6 (bf16 x 3 operands: six products per fp32 product)")
 
         for name in CONV_KERNELS:
             kc = times.get(name)

@@ -75,16 +75,23 @@ int md_costvol_fwd(const float *ref, const float *src, const float *K, const flo
  * otherwise it takes the same route: then one fill instead of two when d_src == d_ref + B*C*h*w).  Poses that scatter a
  * tile's taps over more source cells than the kernel's window holds (an untrained pose network, a camera driving into the
  * scene): with feat_cl the kernel itself switches such hypothesis sub-slices to 16-byte gathers from L2 and queues their
- * d_src terms in LDS; with planar features they take the kernel's per-tap path.  MD_COSTVOL_GATHER_TABLE=1 in the environment
- * (read at every call) selects the build of the fp32 / 2-byte 16 x 4-tile kernel that also merges those terms per source cell in LDS
- * before they leave the CU: for phases with wild poses (5.1x instead of 8.7x the sane time), ~7 % slower when poses are sane; same
- * results to float-atomic ordering.  One launch either way, no state kept
- * between calls (ABI 16: the pose pre-pass of ABI <= 15, with its ring of device-global flag slots, is gone): re-entrant
- * across streams like every other entry point. */
+ * d_src terms in LDS; with planar features they take the kernel's per-tap path (slower for such poses: the trainer hands over
+ * channels-last features).
+ *   flags (ABI 17; the library reads nothing from the process environment): MD_CV_GATHER_TABLE selects the build of the
+ *   16 x 4-tile kernel that also merges those terms per source cell in LDS before they leave the CU: for phases with wild
+ *   poses (5.1x instead of 8.7x the sane time), ~7 % slower when poses are sane; same results to float-atomic ordering.
+ *   census (ABI 17; may be NULL): one device word, 8-byte aligned, overwritten by this launch with
+ *   (hypothesis steps walked in gather mode << 32) | (all hypothesis steps walked) -- what a caller decides the flag of its NEXT
+ *   launch from without a host synchronisation (an asynchronous copy to pinned memory read one call later; movedepth_amd/ops.py
+ *   GatherTablePolicy does exactly that).
+ * One launch either way, no state kept between calls (ABI 16: the pose pre-pass of ABI <= 15, with its ring of device-global
+ * flag slots, is gone): re-entrant across streams like every other entry point. */
+#define MD_CV_GATHER_TABLE 1u
 int md_costvol_bwd(const float *gout, long long g_sb, long long g_sd, long long g_sg, long long g_sp, const float *ref,
                    const float *src, const float *K, const float *invK, const float *pose, const float *hyp,
                    const float *prior, const float *ztrans, float scale_fac, int sched_type, int B, int C, int G,
-                   int h, int w, int D, int feat_cl, float *d_ref, float *d_src, md_stream_t stream);
+                   int h, int w, int D, int feat_cl, float *d_ref, float *d_src, unsigned flags, unsigned long long *census,
+                   md_stream_t stream);
 
 /* The same two entry points with 2-byte feature maps and volume (BASELINE configs 4 and 5: bf16 / fp16 mixed precision;
  * SURVEY 8d table rows 4-5): ref, src, out and gout are bf16 (`_bf16`) or IEEE half (`_f16`) bit patterns (uint16_t
@@ -97,7 +104,8 @@ int md_costvol_fwd_bf16(const uint16_t *ref, const uint16_t *src, const float *K
 int md_costvol_bwd_bf16(const uint16_t *gout, long long g_sb, long long g_sd, long long g_sg, long long g_sp,
                         const uint16_t *ref, const uint16_t *src, const float *K, const float *invK, const float *pose,
                         const float *hyp, const float *prior, const float *ztrans, float scale_fac, int sched_type, int B,
-                        int C, int G, int h, int w, int D, int feat_cl, float *d_ref, float *d_src, md_stream_t stream);
+                        int C, int G, int h, int w, int D, int feat_cl, float *d_ref, float *d_src, unsigned flags, unsigned long long *census,
+                   md_stream_t stream);
 int md_costvol_fwd_f16(const uint16_t *ref, const uint16_t *src, const float *K, const float *invK, const float *pose,
                        const float *hyp, const float *prior, const float *ztrans, float scale_fac, int sched_type, int B,
                        int C, int G, int h, int w, int D, int feat_cl, uint16_t *out, long long out_sb, long long out_sd,
@@ -105,7 +113,8 @@ int md_costvol_fwd_f16(const uint16_t *ref, const uint16_t *src, const float *K,
 int md_costvol_bwd_f16(const uint16_t *gout, long long g_sb, long long g_sd, long long g_sg, long long g_sp,
                        const uint16_t *ref, const uint16_t *src, const float *K, const float *invK, const float *pose,
                        const float *hyp, const float *prior, const float *ztrans, float scale_fac, int sched_type, int B,
-                       int C, int G, int h, int w, int D, int feat_cl, float *d_ref, float *d_src, md_stream_t stream);
+                       int C, int G, int h, int w, int D, int feat_cl, float *d_ref, float *d_src, unsigned flags, unsigned long long *census,
+                   md_stream_t stream);
 
 /* ---- frame-confidence fusion --------------------------------------------------------------
  * trainer.py:349-363: w_f = max_G softmax_G(mean_D vol_f); out = sum_f w_f vol_f / (1e-8 + sum_f w_f).

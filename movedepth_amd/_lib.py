@@ -17,7 +17,10 @@ _sz = ctypes.c_size_t
 
 # md_costvol_fwd / _bwd (and their _bf16 / _f16 twins): ..., B, C, G, h, w, D, feat_cl, ...
 _CV_FWD = [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _ll, _ll, _ll, _ll, _vp]
-_CV_BWD = [_vp, _ll, _ll, _ll, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]
+_u = ctypes.c_uint
+# (ABI 17: d_ref, d_src, flags, census, stream)
+_CV_BWD = [_vp, _ll, _ll, _ll, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _u, _vp, _vp]
+CV_GATHER_TABLE = 1   # MD_CV_GATHER_TABLE
 
 # name -> (restype, argtypes); must list every symbol the header declares (tests/test_cabi.py checks)
 SIGNATURES = {

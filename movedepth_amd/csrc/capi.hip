@@ -13,7 +13,7 @@ void md_set_error(const char *fmt, ...) {
 }
 
 extern "C" const char *md_last_error(void) { return g_err; }
-extern "C" int md_abi_version(void) { return 16; }
+extern "C" int md_abi_version(void) { return 17; }
 
 // ---------------------------------------------------------------- per-kernel timing (measurement only)
 #include <vector>

@@ -37,6 +37,24 @@
 
 #include "md_common.hpp"
 
+// Experiment switches of earlier rounds (all off in the shipped library; tools/ab_build.sh builds a variant with -D...=1 and
+// MOVEDEPTH_HIP_LIB selects it): the library reads nothing from the process environment.
+#ifndef MD_CONV3D_C1_XCD
+#define MD_CONV3D_C1_XCD 0
+#endif
+#ifndef MD_CONV3D_C1_GEN1
+#define MD_CONV3D_C1_GEN1 0
+#endif
+#ifndef MD_CONV3D_C1_GLDS
+#define MD_CONV3D_C1_GLDS 0
+#endif
+#ifndef MD_CONV3D_C1_DS
+#define MD_CONV3D_C1_DS 0
+#endif
+#ifndef MD_CONV3D_C1_PF2
+#define MD_CONV3D_C1_PF2 0
+#endif
+
 
 namespace {
 
@@ -847,15 +865,11 @@ void c1_fwd16_dims(C1Dims &dm) {
     dm.planes = md_cdiv(dm.D, ds);
     dm.dslices = md_cdiv(dm.D, dm.planes);
     // off by default: measured 82.0 / 82.4 us with it against 82.8 / 80.1 us without (the halo re-reads are L2 / MALL hits
-    // either way); MD_CONV3D_C1_XCD=1 switches it on
-    static const bool xcd = [] { const char *e = getenv("MD_CONV3D_C1_XCD"); return e && *e == '1'; }();
-    dm.per_xcd = xcd ? md_cdiv(dm.B * dm.tiles * dm.dslices, 8) : 0;
+    // either way); -DMD_CONV3D_C1_XCD=1 (tools/ab_build.sh) builds it in
+    dm.per_xcd = MD_CONV3D_C1_XCD ? md_cdiv(dm.B * dm.tiles * dm.dslices, 8) : 0;
 }
 
-bool c1_gen1() {  // MD_CONV3D_C1_GEN1=1: the first-generation kernels for every shape (A/B measurements)
-    static const bool v = [] { const char *e = getenv("MD_CONV3D_C1_GEN1"); return e && *e == '1'; }();
-    return v;
-}
+constexpr bool c1_gen1() { return MD_CONV3D_C1_GEN1 != 0; }  // -DMD_CONV3D_C1_GEN1=1: the first-generation kernels for every shape (A/B builds)
 
 }  // namespace
 
@@ -872,9 +886,8 @@ int md_conv3d_c1_fwd(const float *x, const float *wt, long long w_stride_k, long
     const int wl = (w_stride_k == 16 && w_stride_c == 1) ? 0 : (w_stride_k == 1 && w_stride_c == 27) ? 1 : -1;
     if (C == 16 && wl >= 0 && !c1_gen1()) {
         c1_fwd16_dims(dm);
-        // MD_CONV3D_C1_GLDS=1 / 2: LDS-DMA staging, single / double buffered (conv3d_c1_fwd16g_kernel); MD_CONV3D_C1_DS: D slices
-        static const int glds = [] { const char *e = getenv("MD_CONV3D_C1_GLDS"); return e ? atoi(e) : 0; }();
-        static const int dsl = [] { const char *e = getenv("MD_CONV3D_C1_DS"); return e ? atoi(e) : 0; }();
+        // -DMD_CONV3D_C1_GLDS=1 / 2: LDS-DMA staging, single / double buffered (conv3d_c1_fwd16g_kernel); -DMD_CONV3D_C1_DS=n: D slices
+        constexpr int glds = MD_CONV3D_C1_GLDS, dsl = MD_CONV3D_C1_DS;
         if (dsl > 0) { dm.planes = md_cdiv(D, dsl); dm.dslices = md_cdiv(D, dm.planes); dm.per_xcd = 0; }
         const dim3 grid16(dm.per_xcd ? 8 * dm.per_xcd : B * dm.tiles * dm.dslices);
         if (glds && wl == 0) {
@@ -890,7 +903,7 @@ int md_conv3d_c1_fwd(const float *x, const float *wt, long long w_stride_k, long
             MD_CHECK_LAUNCH("md_conv3d_c1_fwd");
             return MD_OK;
         }
-        static const bool pf2 = [] { const char *e = getenv("MD_CONV3D_C1_PF2"); return e && *e == '1'; }();
+        constexpr bool pf2 = MD_CONV3D_C1_PF2 != 0;
         if (wl == 0 && pf2) MD_LAUNCH_TIMED("md_conv3d_c1_fwd", (conv3d_c1_fwd16_kernel<0, true>), grid16, dim3(256), 0, s, x, wt, y, dm);
         else if (wl == 0) MD_LAUNCH_TIMED("md_conv3d_c1_fwd", conv3d_c1_fwd16_kernel<0>, grid16, dim3(256), 0, s, x, wt, y, dm);
         else MD_LAUNCH_TIMED("md_conv3d_c1_fwd", conv3d_c1_fwd16_kernel<1>, grid16, dim3(256), 0, s, x, wt, y, dm);

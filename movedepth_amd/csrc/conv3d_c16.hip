@@ -18,6 +18,17 @@
 // and a second kernel adds the partials in a fixed order in fp64 (deterministic; no float atomics).
 #include "md_common.hpp"
 
+// A/B build switches (tools/ab_build.sh); the library reads nothing from the process environment.
+#ifndef MD_C16_DSLICES
+#define MD_C16_DSLICES 0   // n >= 1: planes per slice = ceil(D / n) instead of c16_dims' choice
+#endif
+#ifndef MD_C16_BF3
+#define MD_C16_BF3 1       // channels-last forward / data gradient on the bf16 matrix pipe with three-piece operands (0: fp32 MFMA)
+#endif
+#ifndef MD_C16_BF3_WGRAD
+#define MD_C16_BF3_WGRAD 1 // the same for the weight gradient
+#endif
+
 namespace {
 
 constexpr int TH = 8, TW = 32, HW_ = TW + 2, HH_ = TH + 2, CELLS = HH_ * HW_;
@@ -810,10 +821,7 @@ int c16_dims(const char *fn, int B, int Ci, int Co, int D, int H, int W, C16Dims
     // Swept at 6x96x48x160 (fwd / data gradient / weight gradient, us): 4 slices (this default, 720 workgroups) 628 / 629 /
     // 701; 6: 656 / 650 / 773; 8: 630 / 624 / 695; 12: 645 / 618 / 788; 16: 663 / 635 / 842 -- the ~60 % of peak is not a
     // tail effect of 720 workgroups on 512 slots.
-    if (const char *e = getenv("MD_C16_DSLICES")) {  // experiment knob: planes per slice = ceil(D / value)
-        const int v = atoi(e);
-        if (v >= 1 && v <= D) ds = v;
-    }
+    if (MD_C16_DSLICES >= 1 && MD_C16_DSLICES <= D) ds = MD_C16_DSLICES;  // A/B builds: planes per slice = ceil(D / value)
     dm.planes = md_cdiv(D, ds);
     dm.dslices = md_cdiv(D, dm.planes);
     return MD_OK;
@@ -831,8 +839,8 @@ static int c16_launch_fwd(const char *fn, const float *in, const float *wt, long
     MD_REQUIRE(in_planar || ((uintptr_t)in % 16) == 0, "%s: a channels-last input volume must be 16-byte aligned", fn);
     C16Dims dm;
     if (int rc = c16_dims(fn, B, Ci, Co, D, H, W, dm)) return rc;
-    // channels-last in and out (what the trainer runs): the bf16 x 3 kernel, 30-column tiles; MD_C16_BF3=0: the fp32-MFMA kernel
-    static const bool bf3 = [] { const char *e = getenv("MD_C16_BF3"); return !(e && *e == '0'); }();
+    // channels-last in and out (what the trainer runs): the bf16 x 3 kernel, 30-column tiles; -DMD_C16_BF3=0: the fp32-MFMA kernel (A/B builds)
+    constexpr bool bf3 = MD_C16_BF3 != 0;
     if (bf3 && !in_planar && !out_planar && ((uintptr_t)out % 16) == 0) {
         C16Dims d3 = dm;
         d3.tiles_x = md_cdiv(W, B3_TW);
@@ -869,7 +877,7 @@ int md_conv3d_c16_bwd_data(const float *gy, const float *wt, long long w_stride_
 
 // the bf16 x 3 weight gradient's tiles are 4 rows high: twice the workgroups (and partials) of the fp32-MFMA kernel's
 static void c16_dims_w3(C16Dims &dm, int H) { dm.tiles = dm.tiles_x * md_cdiv(H, W3_TH); }
-static bool c16_w3_on() { static const bool v = [] { const char *e = getenv("MD_C16_BF3_WGRAD"); return !(e && *e == '0'); }(); return v; }
+static constexpr bool c16_w3_on() { return MD_C16_BF3_WGRAD != 0; }
 
 size_t md_conv3d_c16_bwd_weight_ws_bytes(int B, int D, int H, int W) {
     C16Dims dm;

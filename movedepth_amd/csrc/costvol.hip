@@ -101,6 +101,7 @@ struct CvDims {
     // slices each, workgroups >= nc take 1/fsub of one of the remaining slices (see launch_cl_inst)
     int k1, nc, fsub;
     unsigned long long *stats;   // md_costvol_stats: per-launch counters (null: off)
+    unsigned long long *census;  // backward: this launch's (hypothesis steps walked in gather mode << 32 | all steps), or null
     int fcl;                     // feature maps and their gradients channels-last [B,h,w,C] (channels-last kernels only)
     int xcd_map;                 // item-aligned slices: contiguous ranges per XCD (cv_share)
     float gslack0;               // fcl: ... and by this factor already at the first (whole-slice) attempt: no halving
@@ -721,16 +722,62 @@ __global__ __launch_bounds__(256) void costvol_bwd_kernel(const io_t *__restrict
     }
 }
 
-int env_int(const char *name, int dflt) {
-    const char *e = getenv(name);
-    return (e && *e) ? atoi(e) : dflt;
-}
+// Launch-shape switches of earlier rounds' sweeps.  Compile-time only (tools/ab_build.sh NAME -DMD_COSTVOL_...=v builds a variant,
+// MOVEDEPTH_HIP_LIB selects it): the library reads nothing from the process environment -- what a caller may choose is an
+// argument of the entry point (`flags` of md_costvol_bwd*, include/movedepth_hip.h).
+#ifndef MD_COSTVOL_NWG
+#define MD_COSTVOL_NWG 0            // > 0: forward grid size (workgroups) instead of the occupancy-derived one
+#endif
+#ifndef MD_COSTVOL_NWG_BWD
+#define MD_COSTVOL_NWG_BWD 0
+#endif
+#ifndef MD_COSTVOL_TWO_PHASE_FWD
+#define MD_COSTVOL_TWO_PHASE_FWD 0  // two-phase schedule (launch_cl_inst): backward only
+#endif
+#ifndef MD_COSTVOL_TWO_PHASE_BWD
+#define MD_COSTVOL_TWO_PHASE_BWD 1
+#endif
+#ifndef MD_COSTVOL_XCD_MAP
+#define MD_COSTVOL_XCD_MAP 0        // contiguous slice ranges per XCD (cv_share): measured no gain
+#endif
+#ifndef MD_COSTVOL_XCD_MAP_BWD
+#define MD_COSTVOL_XCD_MAP_BWD 0
+#endif
+#ifndef MD_COSTVOL_BWD_SHAPE0
+#define MD_COSTVOL_BWD_SHAPE0 0     // which window shape the backward's fit test tries first (ClShapes)
+#endif
+#ifndef MD_COSTVOL_MIN_SUB
+#define MD_COSTVOL_MIN_SUB 24       // shortest hypothesis sub-slice a window is staged for (channels-last features)
+#endif
+#ifndef MD_COSTVOL_MIN_SUB_BWD
+#define MD_COSTVOL_MIN_SUB_BWD 24
+#endif
+#ifndef MD_COSTVOL_CPW
+#define MD_COSTVOL_CPW 0            // first-generation kernels: channels per workgroup (0: 16, or 32 for a channels-last volume)
+#endif
+#ifndef MD_COSTVOL_CPW_BWD
+#define MD_COSTVOL_CPW_BWD 8
+#endif
+#ifndef MD_COSTVOL_DSPLIT
+#define MD_COSTVOL_DSPLIT 0         // first-generation kernels: hypothesis slices per item (0: derived)
+#endif
+#ifndef MD_COSTVOL_DSPLIT_BWD
+#define MD_COSTVOL_DSPLIT_BWD 0
+#endif
+#ifndef MD_COSTVOL_CL_FILL
+#define MD_COSTVOL_CL_FILL 1
+#endif
+#ifndef MD_COSTVOL_CL
+#define MD_COSTVOL_CL 1             // 0: never take the channels-last-volume kernels (planar-era kernels for every layout; A/B builds)
+#endif
 
 struct CvPtrs {
     const io_t *gout, *ref, *src;
     const float *K, *invK, *pose, *hyp, *prior, *ztrans;
     io_t *out;
     float *d_ref, *d_src;
+    unsigned flags;               // backward: MD_CV_* bits of the entry point
+    unsigned long long *census;   // backward: (gathered steps << 32 | steps) of this launch, or null
 };
 
 #include "costvol_cl.inc"
@@ -745,7 +792,7 @@ int launch_cl_inst(const CvPtrs &q, const CvDims &dm, hipStream_t stream) {
     if constexpr (BWD) fn = (const void *)cl_bwd_kernel<N, LPP, NW, FUSED, FCL>;
     else fn = (const void *)cl_fwd_kernel<N, LPP, NW, FUSED, FCL>;
     const long long total = (long long)dm.items * dm.D;
-    long long nwg = env_int(BWD ? "MD_COSTVOL_NWG_BWD" : "MD_COSTVOL_NWG", 0);
+    long long nwg = BWD ? MD_COSTVOL_NWG_BWD : MD_COSTVOL_NWG;
     if (nwg <= 0) {
         // resident workgroup slots of this kernel on this chip, queried once per instantiation (the query costs tens of
         // microseconds of host time per call: with it in every launch the kernel started ~15 us late inside the training step)
@@ -781,7 +828,7 @@ int launch_cl_inst(const CvPtrs &q, const CvDims &dm, hipStream_t stream) {
         dm2.fsub = 1;
         // Backward only: measured at config 2, backward 97-103 -> 90-91 us stand-alone and 95.6 -> 90.8 us in the training
         // step; the forward (store-bound, 24-step pieces re-stage their window) got slower, 60 -> 63 us, and keeps plain slices.
-        if (nwg > slots && env_int("MD_COSTVOL_TWO_PHASE", BWD ? 1 : 0)) {
+        if (nwg > slots && (BWD ? MD_COSTVOL_TWO_PHASE_BWD : MD_COSTVOL_TWO_PHASE_FWD)) {
             const long long full = nwg / slots * slots, rest = nwg - full;
             long long f = rest > 0 ? slots / rest : 1;
             while (f > 1 && dm.D / k / f < 8) --f;
@@ -810,15 +857,19 @@ int launch_cl_inst(const CvPtrs &q, const CvDims &dm, hipStream_t stream) {
             if (!whole) MD_CHECK_HIP(hipMemsetAsync(q.d_ref, 0, bytes, stream));
         }
     }
+    if (BWD && q.census) MD_CHECK_HIP(hipMemsetAsync(q.census, 0, sizeof(unsigned long long), stream));
+    dm2.census = BWD ? q.census : nullptr;
     hipEvent_t ev0, ev1;
     md_timing_pair(tname, &ev0, &ev1);
     if constexpr (BWD) {
-        // MD_COSTVOL_GATHER_TABLE=1: the build of the 16 x 4-tile kernel whose gather mode merges a tile's d_src terms per source cell
+        // MD_CV_GATHER_TABLE in `flags`: the build of the 16 x 4-tile kernel whose gather mode merges a tile's d_src terms per source cell
         // in LDS before they leave the CU (costvol_cl.inc, TAB).  For the wild poses of an untrained pose network, where the launch is
-        // bound by the L2's float-atomic rate: 540 -> 314 us at B=6, 48x160, D=96.  Its own instantiation and opt-in because the table
-        // code costs the kernel that carries it: 168 registers + 3 spilled (scratch set-up per launch) and a slower gather walk when
+        // bound by the L2's float-atomic rate: 540 -> 314 us at B=6, 48x160, D=96.  Its own instantiation and the CALLER's choice because the
+        // table code costs the kernel that carries it: 168 registers + 3 spilled (scratch set-up per launch) and a slower gather walk when
         // the table does not pay -- sane poses 61.7 -> 65 us, driving scene 106 -> 123, moderate 122 -> 138 (profiles/r05_costvol_table.txt).
-        const bool table = env_int("MD_COSTVOL_GATHER_TABLE", 0) != 0;   // (read per launch: a trainer may switch it once its poses have settled)
+        // The caller decides from the `census` word of its previous launches (share of the hypothesis steps that ran in gather mode:
+        // movedepth_amd/ops.py GatherTablePolicy); the library keeps no state and reads no environment.
+        const bool table = (q.flags & MD_CV_GATHER_TABLE) != 0;
         if constexpr (FCL && LPP == 4 && NW == 4 && N <= 2) {
             if (table) {
                 hipExtLaunchKernelGGL((cl_bwd_kernel<N, LPP, NW, FUSED, FCL, true>), grid, block, 0, stream, ev0, ev1, 0, q.gout, q.ref, q.src,
@@ -889,20 +940,15 @@ int launch_cl(const CvPtrs &q, CvDims dm, hipStream_t stream) {
 
 template <bool BWD>
 int launch(const CvPtrs &q, CvDims dm, hipStream_t stream) {
-    static const float gslack = [] { const char *e = getenv("MD_COSTVOL_GATHER_SLACK"); const float f = (e && *e) ? (float)atof(e) : MD_CL_GATHER_SLACK; return f > 0.f ? f : MD_CL_GATHER_SLACK; }();
-    dm.gslack = gslack;
-    static const int xcd_map = env_int(BWD ? "MD_COSTVOL_XCD_MAP_BWD" : "MD_COSTVOL_XCD_MAP", 0);
-    dm.xcd_map = xcd_map;
-    static const float gslack0 = [] { const char *e = getenv("MD_COSTVOL_GATHER_SLACK0"); return (e && *e) ? (float)atof(e) : 1e9f; }();
-    dm.gslack0 = gslack0;
-    static const int shape0 = env_int("MD_COSTVOL_BWD_SHAPE0", 0);
-    dm.shape0 = shape0 >= 0 && shape0 < 3 ? shape0 : 0;
+    dm.gslack = MD_CL_GATHER_SLACK;
+    dm.xcd_map = BWD ? MD_COSTVOL_XCD_MAP_BWD : MD_COSTVOL_XCD_MAP;
+    dm.gslack0 = MD_CL_GATHER_SLACK0;
+    dm.shape0 = MD_COSTVOL_BWD_SHAPE0 >= 0 && MD_COSTVOL_BWD_SHAPE0 < 3 ? MD_COSTVOL_BWD_SHAPE0 : 0;
     // 24: a window staged for fewer steps costs more than gathering them (a staging + a d_src window flush are ~25 k cycles of a
     // backward workgroup, ~10 of a forward one).  At B=6, 48x160, D=96, 8 -> 24: driving scene backward 133 -> 105 us, forward at 2 m
     // per frame 83 -> 71, moderate poses 73 -> 66 / 132 -> 126; sane and white-noise priors never get there; wild poses 530 -> 540
     // (profiles/r05_costvol_parallax.txt)
-    static const int min_sub_f = env_int("MD_COSTVOL_MIN_SUB", 24), min_sub_b = env_int("MD_COSTVOL_MIN_SUB_BWD", 24);
-    dm.min_sub = BWD ? min_sub_b : min_sub_f;
+    dm.min_sub = BWD ? MD_COSTVOL_MIN_SUB_BWD : MD_COSTVOL_MIN_SUB;
     if (dm.min_sub < 4) dm.min_sub = 4;
     if (cl_eligible(dm, BWD ? (const void *)q.gout : (const void *)q.out)) return launch_cl<BWD>(q, dm, stream);
     if (dm.fcl) {
@@ -911,6 +957,7 @@ int launch(const CvPtrs &q, CvDims dm, hipStream_t stream) {
         return MD_EINVAL;
     }
     if (BWD) {   // first-generation backward: both gradients accumulate with atomics
+        if (q.census) MD_CHECK_HIP(hipMemsetAsync(q.census, 0, sizeof(unsigned long long), stream));   // (no gather mode in these kernels)
         const size_t bytes = sizeof(float) * (size_t)dm.B * dm.C * dm.h * dm.w;
         if ((char *)q.d_ref + bytes == (char *)q.d_src) {
             MD_CHECK_HIP(hipMemsetAsync(q.d_ref, 0, 2 * bytes, stream));
@@ -935,7 +982,7 @@ int launch_gen1(const CvPtrs &q, CvDims dm, hipStream_t stream, const char *tnam
     // backward keeps 4 x CPW scatter accumulators in registers, so it carries 8.
     // channels-last output: all of a pixel's groups must come from one workgroup to write whole 64-byte lines
     const bool cl_out = !BWD && dm.sg == 1;
-    int cpw_target = env_int(BWD ? "MD_COSTVOL_CPW_BWD" : "MD_COSTVOL_CPW", BWD ? 8 : (cl_out ? 32 : 16));
+    int cpw_target = BWD ? MD_COSTVOL_CPW_BWD : (MD_COSTVOL_CPW > 0 ? MD_COSTVOL_CPW : (cl_out ? 32 : 16));
     int GS = 0;
     for (int cpw = cpw_target; cpw >= 4 && !GS; cpw /= 2)
         if (cpw % N == 0 && dm.G % (cpw / N) == 0) GS = cpw / N;
@@ -961,7 +1008,7 @@ int launch_gen1(const CvPtrs &q, CvDims dm, hipStream_t stream, const char *tnam
     dm.splits = splits;
     dm.items = dm.B * tiles * splits;
     const long long total = (long long)dm.items * dm.D;
-    long long nwg = env_int(BWD ? "MD_COSTVOL_NWG_BWD" : "MD_COSTVOL_NWG", 0);
+    long long nwg = BWD ? MD_COSTVOL_NWG_BWD : MD_COSTVOL_NWG;
     if (nwg <= 0) {
         const int wp = (TW + (CPW >= 32 ? 8 : 16)) * (TH + (CPW >= 32 ? 4 : 8));
         const long long lds = (long long)wp * CPW * 4 * (BWD ? 2 : 1) + ITV_MAX * 4 + 64 +
@@ -970,7 +1017,7 @@ int launch_gen1(const CvPtrs &q, CvDims dm, hipStream_t stream, const char *tnam
         if (per_cu > 8) per_cu = 8;
         if (per_cu < 1) per_cu = 1;
         const long long slots = 256 * per_cu;
-        int dsplit = env_int(BWD ? "MD_COSTVOL_DSPLIT_BWD" : "MD_COSTVOL_DSPLIT", 0);
+        int dsplit = BWD ? MD_COSTVOL_DSPLIT_BWD : MD_COSTVOL_DSPLIT;
         if (dsplit <= 0) {
             dsplit = 1;
             for (int c = 2; c <= dm.D / 8; ++c)
@@ -983,7 +1030,7 @@ int launch_gen1(const CvPtrs &q, CvDims dm, hipStream_t stream, const char *tnam
         // split over exactly `slots` workgroups measured 70.2 us against 74.5 us (same-buffer medians of 8 interleaved runs,
         // 7 of 8 pairs faster) despite ~1/3 of the workgroups staging two windows.  The planar kernels measured
         // the opposite (72 vs 60 us) and keep item-aligned slices.
-        if (cl_out && nwg < slots && total >= slots * 8 && env_int("MD_COSTVOL_CL_FILL", 1)) nwg = slots;
+        if (cl_out && nwg < slots && total >= slots * 8 && MD_COSTVOL_CL_FILL) nwg = slots;
     }
     if (nwg > total) nwg = total;
     if (nwg * ITV_MAX < total) nwg = (total + ITV_MAX - 1) / ITV_MAX;  // a share fits the interval table
@@ -1085,13 +1132,16 @@ extern "C" int MD_CV_NAME(md_costvol_bwd)(const abi_io_t *gout_, long long g_sb,
                               const abi_io_t *src_, const float *K, const float *invK, const float *pose,
                               const float *hyp, const float *prior, const float *ztrans, float scale_fac,
                               int sched_type, int B, int C, int G, int h, int w, int D, int feat_cl, float *d_ref,
-                              float *d_src, md_stream_t stream) {
+                              float *d_src, unsigned flags, unsigned long long *census, md_stream_t stream) {
     const io_t *gout = reinterpret_cast<const io_t *>(gout_), *ref = reinterpret_cast<const io_t *>(ref_),
                *src = reinterpret_cast<const io_t *>(src_);
     int rc = check_common("md_costvol_bwd", ref, src, K, invK, pose, hyp, prior, sched_type, B, C, G, h, w, D);
     if (rc) return rc;
     MD_REQUIRE(gout && d_ref && d_src, "md_costvol_bwd: null gradient tensor");
+    MD_REQUIRE((flags & ~(unsigned)MD_CV_GATHER_TABLE) == 0, "md_costvol_bwd: unknown flag bits 0x%x", flags);
+    MD_REQUIRE(((uintptr_t)census % 8) == 0, "md_costvol_bwd: census must be 8-byte aligned");
     CvPtrs q{};
+    q.flags = flags; q.census = census;
     q.gout = gout; q.ref = ref; q.src = src; q.K = K; q.invK = invK; q.pose = pose; q.hyp = hyp; q.prior = prior;
     q.ztrans = ztrans; q.d_ref = d_ref; q.d_src = d_src;
     CvDims dm{};

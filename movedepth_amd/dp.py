@@ -55,6 +55,7 @@ class GradSync:
         self._pending = [0] * len(self.buckets)
         self._handles = []
         self._hooks = []
+        self.reduce_calls = self.reduce_bytes = 0   # bucket all-reduces issued so far, and their bytes (bench.py config.collectives)
         for bi, (_, ps) in enumerate(self.buckets):
             for p in ps:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(bi)))
@@ -104,6 +105,8 @@ class GradSync:
 
     def _reduce(self, bi):
         flat = self.buckets[bi][0]
+        self.reduce_calls += 1
+        self.reduce_bytes += flat.numel() * flat.element_size()
         if self.direct is not None:
             self.direct(flat)        # on the current (compute) stream; ordered by the stream, nothing to wait for
         else:

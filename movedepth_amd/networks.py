@@ -412,7 +412,7 @@ def convert_hip_sync_batchnorm(module, group=None, fuse_relu=True):
     torch.nn.SyncBatchNorm.convert_sync_batchnorm does for torch's layer).  FusedBNReLU3d layers keep their own kernels and get
     `group` as their sync_group."""
     if isinstance(module, torch.nn.modules.batchnorm._BatchNorm) and not isinstance(module, nn.BatchNorm1d) and \
-            module.track_running_stats and module.num_features % 4 == 0:
+            module.track_running_stats and module.num_features % 4 == 0 and module.momentum is not None:
         return HipSyncBatchNorm.from_batchnorm(module, group)
     if isinstance(module, FusedBNReLU3d):
         module.sync_group = group
@@ -421,8 +421,13 @@ def convert_hip_sync_batchnorm(module, group=None, fuse_relu=True):
         # what the kernels do not take (BatchNorm1d, channel counts that are not multiples of 4, no running statistics) must not
         # silently stay an unsynchronised layer under --ddp --sync_bn: the reference converts EVERY BatchNorm
         # (trainer.py:69-135, convert_sync_batchnorm) -- so does this, with torch's own module for the leftovers
-        if callable(group) and not isinstance(group, torch.distributed.ProcessGroup):   # a rccl_direct.DirectAllReduce: its torch group
-            group = group.group
+        if callable(group) and not isinstance(group, torch.distributed.ProcessGroup):
+            # a rccl_direct.DirectAllReduce: torch's SyncBatchNorm would drive the direct path's OWN communicator from torch's stream
+            # while ncclAllReduce runs on it from the compute stream -- one communicator on two streams, the hang rccl_direct's header
+            # rules out.  The shipped networks have no such layer; a model that does must run without MD_DIRECT_RCCL.
+            raise RuntimeError("convert_hip_sync_batchnorm: %s cannot run on the HIP kernels (BatchNorm1d, channels not a multiple of 4, "
+                               "no running statistics or momentum=None) and the direct-RCCL path is on: run without MD_DIRECT_RCCL=1"
+                               % type(module).__name__)
         return nn.SyncBatchNorm.convert_sync_batchnorm(module, group)
     for name, child in list(module.named_children()):
         new = convert_hip_sync_batchnorm(child, group, fuse_relu)

@@ -158,6 +158,51 @@ def _is_cl(t):
     return t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last) and not t.is_contiguous()
 
 
+class GatherTablePolicy:
+    """Chooses md_costvol_bwd's MD_CV_GATHER_TABLE flag per launch, without a host synchronisation and without anything read from
+    the environment.  Every backward launch leaves its census -- (hypothesis steps walked in gather mode << 32) | all steps -- in a
+    device word; an asynchronous copy brings it to pinned host memory behind the launch, and the NEXT launch reads whatever census
+    has landed by then (this step's earlier volume or the previous step's: poses drift over hundreds of steps, the untrained-pose
+    phase the table kernel exists for lasts that long).  Above `threshold` of the steps gathered (wild poses: ~65 % at config 2's
+    shape; moderate ~27 %, driving scene < 1 %, sane 0: profiles/r05_costvol_wgstats.txt) the cell-table build pays
+    (csrc/costvol.hip launch_cl_inst).  `force` = True / False pins the choice (tests, A/B runs)."""
+
+    def __init__(self, device, threshold=0.45):
+        self.dev = torch.zeros(1, dtype=torch.int64, device=device)
+        self.host = torch.zeros(1, dtype=torch.int64).pin_memory()
+        self.threshold = float(threshold)
+        self.force = None
+        self.launches = self.table_launches = 0
+
+    def gathered_share(self):
+        """Share of the last landed census' hypothesis steps that ran in gather mode (plain read of pinned memory: never waits)."""
+        v = int(self.host[0])
+        g, t = (v >> 32) & 0xFFFFFFFF, v & 0xFFFFFFFF
+        return g / t if t else 0.0
+
+    def flags(self):
+        on = self.force if self.force is not None else self.gathered_share() > self.threshold
+        self.launches += 1
+        self.table_launches += int(bool(on))
+        return _lib.CV_GATHER_TABLE if on else 0
+
+    def after_launch(self):
+        self.host.copy_(self.dev, non_blocking=True)   # stream-ordered behind the launch; the host does not wait for it
+
+
+_GATHER_POLICIES = {}
+
+
+def gather_table_policy(device=None):
+    """The process' policy object of `device` (created on first use)."""
+    idx = torch.cuda.current_device() if device is None else torch.device(device).index
+    if idx is None:
+        idx = torch.cuda.current_device()
+    if idx not in _GATHER_POLICIES:
+        _GATHER_POLICIES[idx] = GatherTablePolicy(torch.device("cuda", idx))
+    return _GATHER_POLICIES[idx]
+
+
 class _CostVolume(torch.autograd.Function):
     """Grouped plane-sweep volume; returns a tensor of logical shape (B,D,G,h,w) over `layout` storage."""
 
@@ -207,9 +252,12 @@ class _CostVolume(torch.autograd.Function):
         else:
             d_both = torch.empty((2,) + tuple(ref.shape), device=ref.device, dtype=torch.float32)
         d_ref, d_src = d_both[0], d_both[1]
+        pol = gather_table_policy(ref.device)
         _timed_call("md_costvol_bwd" + ctx.sfx, _p(g), sb, sd, sg, sp, _p(ref), _p(src), _p(K), _p(invK), _p(pose),
                     _p(hyp if has_hyp else None), _p(prior if has_prior else None), _p(ztrans if has_z else None),
-                    scale_fac, sched_type, B, C, G, h, w, D, int(ctx.fcl), _p(d_ref), _p(d_src), _stream())
+                    scale_fac, sched_type, B, C, G, h, w, D, int(ctx.fcl), _p(d_ref), _p(d_src), pol.flags(), _p(pol.dev),
+                    _stream())
+        pol.after_launch()
         return (d_ref.to(ctx.io), d_src.to(ctx.io)) + (None,) * 11
 
 
@@ -1078,8 +1126,13 @@ def _bn_ws(device, stream):
     return ws[1]
 
 
+GROUP_ALL_REDUCE = [0, 0]   # statistics all-reduces issued by the BatchNorm layers of this process: calls, bytes (bench.py config.collectives)
+
+
 def _group_all_reduce(t, group):
     """in-place sum over `group`: a rccl_direct.DirectAllReduce (RCCL on the current stream) or a torch.distributed group"""
+    GROUP_ALL_REDUCE[0] += 1
+    GROUP_ALL_REDUCE[1] += t.numel() * t.element_size()
     if callable(group):
         group(t)
     else:

@@ -36,7 +36,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, s), "libmovedepth_hip.so does not export %s" % s
     # the ctypes binding covers the whole header, and nothing else
     assert sorted(_lib.SIGNATURES) == header_symbols()
-    assert _lib.load().md_abi_version() == 16
+    assert _lib.load().md_abi_version() == 17
 
 
 def test_invalid_arguments_fail_loudly_without_a_gpu():

@@ -316,6 +316,75 @@ def test_costvol_config4_launch_shapes_vs_oracle(ops, oracle_lib, C, B, dtype, f
     assert relerr(host(s.grad), c["exp_dsrc"]) <= tol
 
 
+def _half_launch_check(ops, r, s, c_or, exp, exp_dref, exp_dsrc, gout, run, what, dtype=torch.float16, tol_rounded=2e-4, tol_exact=5e-4):
+    """Volume against the oracle's fp32 volume rounded to `dtype` (norm-wise `tol_rounded`) and against the exact one (`tol_exact`),
+    gradients (fp32 sums of rounded records, returned in `dtype`) against the oracle's: the bounds of test_costvol_half_io_vs_oracle."""
+    vol = run(r, s)
+    assert vol.dtype == dtype
+    got = host(vol)
+    rel_r, _ = relerr_chunked(got, torch.from_numpy(exp).to(dtype).float().numpy())
+    rel, _ = relerr_chunked(got, exp)
+    print("%s: volume rel %.2e against the rounded oracle, %.2e against the exact one" % (what, rel_r, rel))
+    assert rel_r <= tol_rounded and rel <= tol_exact, (rel_r, rel)
+    del got
+    vol.backward(torch.from_numpy(gout).to(dtype).cuda())
+    assert r.grad.dtype == dtype and s.grad.dtype == dtype
+    e_r, e_s = relerr(host(r.grad), exp_dref), relerr(host(s.grad), exp_dsrc)
+    print("%s: d_ref rel %.2e, d_src rel %.2e" % (what, e_r, e_s))
+    assert e_r <= tol_exact and e_s <= tol_exact, (e_r, e_s)
+
+
+@pytest.mark.parametrize("feat", FEATS)
+@pytest.mark.parametrize("prior_kind", ["smooth", "white"])
+def test_costvol_config5_launch_shape_vs_oracle(ops, oracle_lib, prior_kind, feat):
+    """BASELINE config 5's volume launch -- B=6, C=32, G=16, 48x160, D=96, fp16 feature maps and volume, velocity-guided hypotheses
+    (layers.py:370-398 with z = z_scale * T[2,3], trainer.py:337-341), schedule fused, channels-last volume -- against the oracle at
+    the launch shape bench.py's config-5 line times: the 720-item decomposition, its hypothesis slices and
+    sub-slices in the 2-byte build (8-byte records, the raw prefetch queue of the backward).  Both feature layouts, smooth and
+    white-noise priors.  The oracle gets the ROUNDED features / gradient as floats; tolerances of test_costvol_half_io_vs_oracle:
+    2e-4 norm-wise against the oracle's volume rounded to fp16, 5e-4 against the exact one and for both gradients.
+    Reference: layers.py:778-794, trainer.py:349-363 (one lookup frame's volume; the N-frame fusion is a10 / test_fuse_*)."""
+    c = full_size_case(oracle_lib, np.random.default_rng(23), 6, 32, 16, 48, 160, 96, prior_kind, dtype=torch.float16)
+    r, s = feat_dev(c["ref"], feat, dtype=torch.float16), feat_dev(c["src"], feat, dtype=torch.float16)
+
+    def run(r, s):
+        return ops.costvol_grouped(r, s, dev(c["K"]), dev(c["invK"]), dev(c["pose"]), 16, prior=dev(c["prior"]), ndepth=96,
+                                   scale_fac=0.3, z_trans=dev(c["z"]), type="inverse", layout="ndhwc")
+    _half_launch_check(ops, r, s, c, c["exp"], c["exp_dref"], c["exp_dsrc"], c["gout"], run, "config-5 launch shape (%s prior, %s)" % (prior_kind, feat))
+    check_grad_layout(r, feat)
+    check_grad_layout(s, feat)
+
+
+@pytest.mark.parametrize("feat", FEATS)
+@pytest.mark.parametrize("case", ["driving_1m", "driving_2m", "moderate"])
+def test_costvol_parallax_cases_launch_shape_fp16_vs_oracle(ops, oracle_lib, case, feat):
+    """The three parallax cases of test_costvol_parallax_cases_launch_shape_vs_oracle in fp16 (config 5's element type): the 2-byte
+    build's windows in three shapes, gathered sub-slices with queued d_src terms, tiles whose sweep leaves the image.  White-noise
+    features and gradient, rounded to fp16 before the oracle sees them.  Reference: layers.py:778-794, trainer.py:351-363."""
+    from movedepth_amd.synthetic import driving_scene
+    rng = np.random.default_rng(78)
+    B, C, G, h, w, D = 6, 32, 16, 48, 160, 96
+    rnd = lambda a: torch.from_numpy(a).to(torch.float16).float().numpy()
+    ref = rnd(rng.standard_normal((B, C, h, w)).astype(np.float32))
+    src = rnd(rng.standard_normal((B, C, h, w)).astype(np.float32))
+    K, invK = kitti_K(h, w, B)
+    if case == "moderate":
+        prior = (2 + 20 * smooth_field(rng, (B, 1, h, w), 12, 0, 1)).astype(np.float32)
+        pose = rand_pose(oracle_lib, rng, B, 0.05, 0.3)
+    else:
+        prior, pose = driving_scene(B, h, w, speed=1.0 if case == "driving_1m" else 2.0)
+    hyp = oracle_lib.schedule_depth_range(prior, D, 0.3, None, "inverse")
+    gout = rnd(rng.standard_normal((B, D, G, h, w)).astype(np.float32))
+    exp = oracle_lib.costvol_grouped(ref, src, K, invK, hyp, pose, G)
+    exp_dref, exp_dsrc = oracle_lib.costvol_grouped_bwd(gout, ref, src, K, invK, hyp, pose)
+    r, s = feat_dev(ref, feat, dtype=torch.float16), feat_dev(src, feat, dtype=torch.float16)
+
+    def run(r, s):
+        return ops.costvol_grouped(r, s, dev(K), dev(invK), dev(pose), G, prior=dev(prior), ndepth=D, scale_fac=0.3, type="inverse",
+                                   layout="ndhwc")
+    _half_launch_check(ops, r, s, None, exp, exp_dref, exp_dsrc, gout, run, "fp16 parallax case %s (%s)" % (case, feat))
+
+
 @pytest.mark.parametrize("feat", FEATS)
 @pytest.mark.parametrize("w,h", [(256, 80), (512, 160)])
 def test_costvol_wide_coordinates_white_noise(ops, oracle_lib, w, h, feat):
@@ -373,10 +442,11 @@ def test_costvol_near_prior_carried_sums_vs_oracle(ops, oracle_lib, C, feat):
 
 @pytest.mark.parametrize("feat", FEATS)
 def test_costvol_wild_poses_backward_fallback_vs_oracle(ops, oracle_lib, feat):
-    """Poses of an untrained pose network (axis-angle ~ N(0, 0.3^2) rad, translation ~ N(0, 2^2)): md_costvol_bwd's pre-pass
-    flags the samples whose taps would thrash the channels-last kernel's window and hands them to the first-generation backward
-    in a second launch (csrc/costvol.hip launch_cl); one sample of the batch keeps a sane pose and stays on the normal kernel.
-    Volume and both gradients against the oracle (reference layers.py:778-794, zeros padding: no cliff in grid_sample)."""
+    """Poses of an untrained pose network (axis-angle ~ N(0, 0.3^2) rad, translation ~ N(0, 2^2)); one sample of the batch keeps a
+    sane pose.  One launch in either feature layout: channels-last features switch the wild sub-slices to L2 gathers with queued
+    d_src terms inside the kernel, planar features take the kernel's per-tap miss path.  Volume and both gradients against the
+    oracle (reference layers.py:778-794, zeros padding: no cliff in grid_sample); the launch's census word reports the gathered
+    share the trainer's table policy reads (ops.GatherTablePolicy)."""
     rng = np.random.default_rng(77)
     B, C, G, h, w, D = 3, 32, 16, 48, 160, 32
     ref = smooth_field(rng, (B, C, h, w), 3, -1, 1)
@@ -396,20 +466,25 @@ def test_costvol_wild_poses_backward_fallback_vs_oracle(ops, oracle_lib, feat):
         assert_close(host(vol), exp, what="volume")
         vol.backward(dev(gout))
         torch.cuda.synchronize()
-        t = ops.library_kernel_times_us(["md_costvol_bwd", "md_costvol_bwd_wild"])
+        t = ops.library_kernel_times_us(["md_costvol_bwd"])
     finally:
         ops.enable_library_kernel_timing(False)
-    # ONE launch in either feature layout: channels-last features switch the wild sub-slices to L2 gathers with queued d_src terms
-    # inside the kernel; planar features take the kernel's per-tap miss path (the pose pre-pass + second launch of rounds 3-4, with
-    # its ring of device-global flags, is gone)
-    assert t["md_costvol_bwd"]["launches"] == 1 and "md_costvol_bwd_wild" not in t, t
+    assert t["md_costvol_bwd"]["launches"] == 1, t
+    pol = ops.gather_table_policy()
+    torch.cuda.synchronize()
+    v = int(pol.dev.item())
+    assert (v & 0xFFFFFFFF) == B * (h // 4) * (w // 16) * D, hex(v)     # every hypothesis step of every 16 x 4 tile, once
+    if feat == "nhwc":
+        assert 0.3 < pol.gathered_share() < 0.9, pol.gathered_share()   # two of three samples wild
+    else:
+        assert (v >> 32) == 0                                            # planar features never gather
     assert_close(host(r.grad), exp_dref, what="d_ref")
     assert_close(host(s.grad), exp_dsrc, what="d_src")
 
 
 @pytest.mark.parametrize("case", ["wild", "moderate", "driving_2m"])
-def test_costvol_backward_cell_table_vs_oracle(ops, oracle_lib, case, monkeypatch):
-    """MD_COSTVOL_GATHER_TABLE=1: the backward instantiation whose gather mode merges a tile's d_src terms per source cell in LDS
+def test_costvol_backward_cell_table_vs_oracle(ops, oracle_lib, case):
+    """MD_CV_GATHER_TABLE (md_costvol_bwd's `flags`, pinned here through the policy object): the backward instantiation whose gather mode merges a tile's d_src terms per source cell in LDS
     (csrc/costvol_cl.inc, TAB: cell-keyed slots in the idle d_src window, a taken slot falls back to the queue, the table leaves the CU
     every 32 steps) at config 2's launch shape, channels-last features: wild poses (every slice gathered, slots contended), moderate
     poses and the driving scene at 2 m per frame (windows and gathered ranges in one workgroup).  White-noise features and gradient.
@@ -428,7 +503,8 @@ def test_costvol_backward_cell_table_vs_oracle(ops, oracle_lib, case, monkeypatc
     hyp = oracle_lib.schedule_depth_range(prior, D, 0.3, None, "inverse")
     gout = rng.standard_normal((B, D, G, h, w)).astype(np.float32)
     exp_dref, exp_dsrc = oracle_lib.costvol_grouped_bwd(gout, ref, src, K, invK, hyp, pose)
-    monkeypatch.setenv("MD_COSTVOL_GATHER_TABLE", "1")
+    pol = ops.gather_table_policy()
+    pol.force = True
     ops.enable_library_kernel_timing(True)
     try:
         r, s = feat_dev(ref, "nhwc"), feat_dev(src, "nhwc")
@@ -439,9 +515,43 @@ def test_costvol_backward_cell_table_vs_oracle(ops, oracle_lib, case, monkeypatc
         t = ops.library_kernel_times_us(["md_costvol_bwd"])
     finally:
         ops.enable_library_kernel_timing(False)
+        pol.force = None
     assert t["md_costvol_bwd"]["launches"] == 1, t
     assert_close(host(r.grad), exp_dref, what="d_ref")
     assert_close(host(s.grad), exp_dsrc, what="d_src")
+    share = pol.gathered_share()
+    assert (share > 0.45) == (case == "wild"), (case, share)   # the threshold of the automatic choice separates the three regimes
+
+
+def test_costvol_gather_table_policy_follows_the_poses(ops, oracle_lib):
+    """The trainer's automatic choice (ops.GatherTablePolicy; no environment variable, no host synchronisation): the backward of
+    a wild-pose volume leaves a census above the threshold, so the NEXT backward runs the cell-table build; a sane-pose launch
+    brings it back.  Gradients of every launch against the oracle (autograd of layers.py:784-792)."""
+    rng = np.random.default_rng(83)
+    B, C, G, h, w, D = 2, 32, 16, 48, 160, 32
+    ref = rng.standard_normal((B, C, h, w)).astype(np.float32)
+    src = rng.standard_normal((B, C, h, w)).astype(np.float32)
+    K, invK = kitti_K(h, w, B)
+    prior = (2 + 20 * smooth_field(rng, (B, 1, h, w), 12, 0, 1)).astype(np.float32)
+    hyp = oracle_lib.schedule_depth_range(prior, D, 0.3, None, "inverse")
+    gout = rng.standard_normal((B, D, G, h, w)).astype(np.float32)
+    poses = {"wild": rand_pose(oracle_lib, rng, B, 0.3, 2.0), "sane": rand_pose(oracle_lib, rng, B, 0.01, 0.05)}
+    exp = {k: oracle_lib.costvol_grouped_bwd(gout, ref, src, K, invK, hyp, p) for k, p in poses.items()}
+    pol = ops.gather_table_policy()
+    pol.force = None
+    torch.cuda.synchronize()
+    pol.host.zero_()
+    seen = []
+    for case in ("wild", "wild", "sane", "sane"):
+        r, s = feat_dev(ref, "nhwc"), feat_dev(src, "nhwc")
+        vol = ops.costvol_grouped(r, s, dev(K), dev(invK), dev(poses[case]), G, prior=dev(prior), ndepth=D, scale_fac=0.3, layout="ndhwc")
+        before = pol.table_launches
+        vol.backward(dev(gout))
+        seen.append(pol.table_launches - before)
+        torch.cuda.synchronize()          # (the test waits so that the census has landed; a trainer simply reads it a launch later)
+        assert_close(host(r.grad), exp[case][0], what="d_ref " + case)
+        assert_close(host(s.grad), exp[case][1], what="d_src " + case)
+    assert seen == [0, 1, 1, 0], seen
 
 
 @pytest.mark.parametrize("feat", FEATS)
