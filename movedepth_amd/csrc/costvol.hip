@@ -100,6 +100,7 @@ struct CvDims {
     // channels-last kernels, two-phase schedule (0 = plain linear shares): workgroups [0, nc) take one of the items' k1 equal
     // slices each, workgroups >= nc take 1/fsub of one of the remaining slices (see launch_cl_inst)
     int k1, nc, fsub;
+    int split;                   // forward, k1 == 2: hypothesis steps of an item's first half (0: equal halves); see launch_cl_inst
     unsigned long long *stats;   // md_costvol_stats: per-launch counters (null: off)
     unsigned long long *census;  // backward: this launch's (hypothesis steps walked in gather mode << 32 | all steps), or null
     int fcl;                     // feature maps and their gradients channels-last [B,h,w,C] (channels-last kernels only)
@@ -162,9 +163,12 @@ __device__ __forceinline__ void cv_share(const CvDims &dm, long long &lo, long l
         bid = x * n8 + min(x, r) + (bid >> 3);
     }
     const int sl = bid < dm.nc ? bid : dm.nc + (bid - dm.nc) / dm.fsub;  // coarse slice
-    const int item = sl / dm.k1, part = sl - item * dm.k1;
-    const long long l0 = (long long)item * dm.D + (long long)part * dm.D / dm.k1;
-    const long long l1 = (long long)item * dm.D + (long long)(part + 1) * dm.D / dm.k1;
+    int item = sl / dm.k1, part = sl - item * dm.k1;
+    if (dm.split > 0) { part = sl / dm.items; item = sl - part * dm.items; }   // uneven halves: every item's long half first
+    // first step of part p of an item: p D / k1, or -- two uneven halves (launch_cl_inst) -- `split` for p == 1
+    auto cut = [&](int p_) -> long long { return (dm.split > 0 && p_ == 1) ? (long long)dm.split : (long long)p_ * dm.D / dm.k1; };
+    const long long l0 = (long long)item * dm.D + cut(part);
+    const long long l1 = (long long)item * dm.D + cut(part + 1);
     if (bid < dm.nc) {
         lo = l0;
         hi = l1;
@@ -728,6 +732,10 @@ __global__ __launch_bounds__(256) void costvol_bwd_kernel(const io_t *__restrict
 #ifndef MD_COSTVOL_NWG
 #define MD_COSTVOL_NWG 0            // > 0: forward grid size (workgroups) instead of the occupancy-derived one
 #endif
+#ifndef MD_COSTVOL_FWD_SPLIT_NUM
+#define MD_COSTVOL_FWD_SPLIT_NUM 0   // forward, two slices per item: first slice = D * NUM / DEN steps (0: equal halves)
+#define MD_COSTVOL_FWD_SPLIT_DEN 1
+#endif
 #ifndef MD_COSTVOL_NWG_BWD
 #define MD_COSTVOL_NWG_BWD 0
 #endif
@@ -788,6 +796,7 @@ template <bool BWD, int N, int LPP, int NW, bool FUSED, bool FCL>
 int launch_cl_inst(const CvPtrs &q, const CvDims &dm, hipStream_t stream) {
     CvDims dm2 = dm;
     dm2.k1 = dm2.nc = dm2.fsub = 0;
+    dm2.split = 0;
     const void *fn;   // (if constexpr: only the direction's own kernel is instantiated)
     if constexpr (BWD) fn = (const void *)cl_bwd_kernel<N, LPP, NW, FUSED, FCL>;
     else fn = (const void *)cl_fwd_kernel<N, LPP, NW, FUSED, FCL>;
@@ -839,6 +848,15 @@ int launch_cl_inst(const CvPtrs &q, const CvDims &dm, hipStream_t stream) {
             }
         }
     }
+#if MD_COSTVOL_FWD_SPLIT_NUM
+    // Experiment (round 6): two UNEVEN halves per item, all long halves first.  Equal halves start, stage and walk in lockstep: on
+    // every CU the two resident workgroups sit in their fixed phase (set-up + staging: memory round trips, no stores) at the same
+    // time and compete for the store path at the same time.
+    if (!BWD && dm2.k1 == 2 && dm2.fsub == 1 && nwg == 2 * (long long)dm.items) {
+        int sp = (int)((long long)dm.D * MD_COSTVOL_FWD_SPLIT_NUM / MD_COSTVOL_FWD_SPLIT_DEN) & ~3;
+        if (sp >= 8 && dm.D - sp >= 8 && sp <= ITV_MAX) dm2.split = sp;
+    }
+#endif
     if (dm2.k1 > 0 && (dm.D + dm2.k1 - 1) / dm2.k1 > ITV_MAX) dm2.k1 = 0;  // an item-aligned slice (up to ceil(D / k) steps) must fit the interval table: plain shares
     if (nwg > total) { nwg = total; dm2.k1 = 0; }
     if (nwg * ITV_MAX < total) { nwg = (total + ITV_MAX - 1) / ITV_MAX; dm2.k1 = 0; }  // a share fits the interval table

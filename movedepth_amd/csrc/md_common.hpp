@@ -294,6 +294,23 @@ __device__ __forceinline__ float md_wave_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+// min / max over the 64 lanes with DPP moves only (the butterflies of md_wave_sum_dpp; `old` = the lane's own value, so a lane a
+// row mask leaves out keeps it: min and max are idempotent).  All 64 lanes must be active.  The __shfl_xor versions below go
+// through the LDS crossbar: 24 ds_bpermute round trips per window fit in the plane-sweep kernels' staging.
+#define MD_DPP_RED(name, OP)                                                                                              \
+    __device__ __forceinline__ int name(int v) {                                                                          \
+        v = OP(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false));                                              \
+        v = OP(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false));                                              \
+        v = OP(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xF, 0xF, false));                                             \
+        v = OP(v, __builtin_amdgcn_update_dpp(v, v, 0x140, 0xF, 0xF, false));                                             \
+        v = OP(v, __builtin_amdgcn_update_dpp(v, v, 0x142, 0xA, 0xF, false));                                             \
+        v = OP(v, __builtin_amdgcn_update_dpp(v, v, 0x143, 0xC, 0xF, false));                                             \
+        return __builtin_amdgcn_readlane(v, 63);                                                                          \
+    }
+MD_DPP_RED(md_wave_min_dpp, min)
+MD_DPP_RED(md_wave_max_dpp, max)
+#undef MD_DPP_RED
+
 __device__ __forceinline__ int md_wave_min(int v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));

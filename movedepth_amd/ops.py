@@ -909,7 +909,7 @@ def _is_planar(t):
 def _w_for_forward(w):
     """The weight with its OUTPUT-channel stride 1 (storage order ci, tap, co).  A workgroup of the bf16 x 3 kernels gathers its 120 weights
     per lane straight from memory, lane = output channel (forward) or input channel (data gradient): with the lane index strided by
-    Ci * 27 floats that prologue cost the forward 28 us of 387 at 16 -> 16 and 80 of 318 at 32 -> 32 (tools/r05/cb_wlayout.py); a
+    Ci * 27 floats that prologue cost the forward 28 us of 387 at 16 -> 16 and 80 of 318 at 32 -> 32 (profiles/r05_conv3d_channel_blocks.txt); a
     transposed copy of the 27-110 KB tensor is one small kernel."""
     if w.stride(0) == 1:
         return w

@@ -97,7 +97,7 @@ class Trainer:
         self.models["reg3d"].hip_prob = bool(opt.hip_prob_conv)
         self.models["reg3d"].hip_conv0_wgrad = opt.hip_conv0 != "none"
         if hasattr(self.models["reg3d"], "conv2") and isinstance(self.models["reg3d"].conv2, networks.ConvBnReLU3D):
-            # 32 -> 32 only: at 64 and 128 channels the 16 / 64 block launches lose to the library (tools/r05/cb_bench.py)
+            # 32 -> 32 only: at 64 and 128 channels the 16 / 64 block launches lose to the library (profiles/r05_conv3d_channel_blocks.txt)
             self.models["reg3d"].conv2.hip_cb = bool(getattr(opt, "hip_conv2", 1)) and self.models["reg3d"].conv2.conv.in_channels == 32
         self.models["reg3d"].lib_conv0_fwd_dgrad = opt.hip_conv0 == "wgrad"
         self.vol_layout = "bgd"
