@@ -84,14 +84,26 @@ int md_costvol_fwd(const float *ref, const float *src, const float *K, const flo
  *   (hypothesis steps walked in gather mode << 32) | (all hypothesis steps walked) -- what a caller decides the flag of its NEXT
  *   launch from without a host synchronisation (an asynchronous copy to pinned memory read one call later; movedepth_amd/ops.py
  *   GatherTablePolicy does exactly that).
+ *   shares, n_shares, cost (ABI 17; NULL / 0 / NULL: the library's own equal partition, nothing recorded; taken by the
+ *   channels-last-volume kernels only): every workgroup of the backward is resident at once, so no hardware scheduler evens out
+ *   what parallax makes uneven -- the launch lasts as long as its slowest tile (workgroup lifetimes max / mean 1.4-1.5 on driving
+ *   scenes).  `cost`: device array of md_costvol_bwd_plan's `items` counters, overwritten with the shader cycles the launch spent
+ *   per item (tile of 16 x 4 pixels of one sample, all D hypotheses).  `shares`: device array of n_shares pairs [lo, hi) in units
+ *   of hypothesis steps (item * D + d), one pair per workgroup, together covering [0, items * D) exactly once -- a partition the
+ *   caller computes from the `cost` of an earlier launch on similar poses (movedepth_amd/ops.py BackwardPolicy: equal COST per
+ *   workgroup instead of equal steps; asynchronous copies, no host synchronisation).  A pair may span items and may be empty.
  * One launch either way, no state kept between calls (ABI 16: the pose pre-pass of ABI <= 15, with its ring of device-global
  * flag slots, is gone): re-entrant across streams like every other entry point. */
 #define MD_CV_GATHER_TABLE 1u
+/* Launch geometry of md_costvol_bwd* for a channels-last volume (B,D,h,w,G): the number of work items (what `cost` counts and
+ * `shares` partitions, in units of D steps each) and the number of workgroups of the library's own partition (a sensible n_shares).
+ * items = 0: this problem runs on the planar-era kernels, which take neither. */
+int md_costvol_bwd_plan(int B, int C, int G, int h, int w, int D, int feat_cl, int *items, int *workgroups);
 int md_costvol_bwd(const float *gout, long long g_sb, long long g_sd, long long g_sg, long long g_sp, const float *ref,
                    const float *src, const float *K, const float *invK, const float *pose, const float *hyp,
                    const float *prior, const float *ztrans, float scale_fac, int sched_type, int B, int C, int G,
                    int h, int w, int D, int feat_cl, float *d_ref, float *d_src, unsigned flags, unsigned long long *census,
-                   md_stream_t stream);
+                   const long long *shares, int n_shares, unsigned *cost, md_stream_t stream);
 
 /* The same two entry points with 2-byte feature maps and volume (BASELINE configs 4 and 5: bf16 / fp16 mixed precision;
  * SURVEY 8d table rows 4-5): ref, src, out and gout are bf16 (`_bf16`) or IEEE half (`_f16`) bit patterns (uint16_t
@@ -105,7 +117,7 @@ int md_costvol_bwd_bf16(const uint16_t *gout, long long g_sb, long long g_sd, lo
                         const uint16_t *ref, const uint16_t *src, const float *K, const float *invK, const float *pose,
                         const float *hyp, const float *prior, const float *ztrans, float scale_fac, int sched_type, int B,
                         int C, int G, int h, int w, int D, int feat_cl, float *d_ref, float *d_src, unsigned flags, unsigned long long *census,
-                   md_stream_t stream);
+                   const long long *shares, int n_shares, unsigned *cost, md_stream_t stream);
 int md_costvol_fwd_f16(const uint16_t *ref, const uint16_t *src, const float *K, const float *invK, const float *pose,
                        const float *hyp, const float *prior, const float *ztrans, float scale_fac, int sched_type, int B,
                        int C, int G, int h, int w, int D, int feat_cl, uint16_t *out, long long out_sb, long long out_sd,
@@ -114,7 +126,7 @@ int md_costvol_bwd_f16(const uint16_t *gout, long long g_sb, long long g_sd, lon
                        const uint16_t *ref, const uint16_t *src, const float *K, const float *invK, const float *pose,
                        const float *hyp, const float *prior, const float *ztrans, float scale_fac, int sched_type, int B,
                        int C, int G, int h, int w, int D, int feat_cl, float *d_ref, float *d_src, unsigned flags, unsigned long long *census,
-                   md_stream_t stream);
+                   const long long *shares, int n_shares, unsigned *cost, md_stream_t stream);
 
 /* ---- frame-confidence fusion --------------------------------------------------------------
  * trainer.py:349-363: w_f = max_G softmax_G(mean_D vol_f); out = sum_f w_f vol_f / (1e-8 + sum_f w_f).

@@ -18,8 +18,8 @@ _sz = ctypes.c_size_t
 # md_costvol_fwd / _bwd (and their _bf16 / _f16 twins): ..., B, C, G, h, w, D, feat_cl, ...
 _CV_FWD = [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _ll, _ll, _ll, _ll, _vp]
 _u = ctypes.c_uint
-# (ABI 17: d_ref, d_src, flags, census, stream)
-_CV_BWD = [_vp, _ll, _ll, _ll, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _u, _vp, _vp]
+# (ABI 17: d_ref, d_src, flags, census, shares, n_shares, cost, stream)
+_CV_BWD = [_vp, _ll, _ll, _ll, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _u, _vp, _vp, _i, _vp, _vp]
 CV_GATHER_TABLE = 1   # MD_CV_GATHER_TABLE
 
 # name -> (restype, argtypes); must list every symbol the header declares (tests/test_cabi.py checks)
@@ -29,6 +29,7 @@ SIGNATURES = {
     "md_schedule_depth_range": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp]),
     "md_costvol_fwd": (_i, _CV_FWD),
     "md_costvol_bwd": (_i, _CV_BWD),
+    "md_costvol_bwd_plan": (_i, [_i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "md_costvol_fwd_bf16": (_i, _CV_FWD),
     "md_costvol_bwd_bf16": (_i, _CV_BWD),
     "md_costvol_fwd_f16": (_i, _CV_FWD),

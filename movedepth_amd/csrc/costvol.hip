@@ -100,9 +100,10 @@ struct CvDims {
     // channels-last kernels, two-phase schedule (0 = plain linear shares): workgroups [0, nc) take one of the items' k1 equal
     // slices each, workgroups >= nc take 1/fsub of one of the remaining slices (see launch_cl_inst)
     int k1, nc, fsub;
-    int split;                   // forward, k1 == 2: hypothesis steps of an item's first half (0: equal halves); see launch_cl_inst
     unsigned long long *stats;   // md_costvol_stats: per-launch counters (null: off)
     unsigned long long *census;  // backward: this launch's (hypothesis steps walked in gather mode << 32 | all steps), or null
+    const long long *shares;     // backward: the caller's partition, [lo, hi) of the items x D steps per workgroup (null: the library's)
+    unsigned *cost;              // backward: per item, the shader cycles the workgroups that walked it took (null: not recorded)
     int fcl;                     // feature maps and their gradients channels-last [B,h,w,C] (channels-last kernels only)
     int xcd_map;                 // item-aligned slices: contiguous ranges per XCD (cv_share)
     float gslack0;               // fcl: ... and by this factor already at the first (whole-slice) attempt: no halving
@@ -144,10 +145,11 @@ struct Slots {
 // the chip's workgroup slots and every workgroup takes an equal, contiguous share of the items x D hypothesis
 // steps (a workgroup's share may span two items): perfectly balanced for any B, image size and D, no tail round.
 struct Seg {
-    int b, tile, gs, d0, d1;
+    int b, tile, gs, d0, d1, item;
 };
 // This workgroup's share [lo, hi) of the items x D hypothesis steps.
 __device__ __forceinline__ void cv_share(const CvDims &dm, long long &lo, long long &hi) {
+    if (dm.shares) { lo = dm.shares[2 * blockIdx.x]; hi = dm.shares[2 * blockIdx.x + 1]; return; }
     const long long total = (long long)dm.items * dm.D;
     if (dm.k1 <= 0) {
         lo = total * blockIdx.x / gridDim.x;
@@ -163,12 +165,9 @@ __device__ __forceinline__ void cv_share(const CvDims &dm, long long &lo, long l
         bid = x * n8 + min(x, r) + (bid >> 3);
     }
     const int sl = bid < dm.nc ? bid : dm.nc + (bid - dm.nc) / dm.fsub;  // coarse slice
-    int item = sl / dm.k1, part = sl - item * dm.k1;
-    if (dm.split > 0) { part = sl / dm.items; item = sl - part * dm.items; }   // uneven halves: every item's long half first
-    // first step of part p of an item: p D / k1, or -- two uneven halves (launch_cl_inst) -- `split` for p == 1
-    auto cut = [&](int p_) -> long long { return (dm.split > 0 && p_ == 1) ? (long long)dm.split : (long long)p_ * dm.D / dm.k1; };
-    const long long l0 = (long long)item * dm.D + cut(part);
-    const long long l1 = (long long)item * dm.D + cut(part + 1);
+    const int item = sl / dm.k1, part = sl - item * dm.k1;
+    const long long l0 = (long long)item * dm.D + (long long)part * dm.D / dm.k1;
+    const long long l1 = (long long)item * dm.D + (long long)(part + 1) * dm.D / dm.k1;
     if (bid < dm.nc) {
         lo = l0;
         hi = l1;
@@ -182,6 +181,7 @@ __device__ __forceinline__ void cv_share(const CvDims &dm, long long &lo, long l
 __device__ __forceinline__ bool next_segment(const CvDims &dm, long long &lo, long long hi, Seg &sg) {
     if (lo >= hi) return false;
     const int item = (int)(lo / dm.D);
+    sg.item = item;
     sg.d0 = (int)(lo % dm.D);
     const long long left = hi - lo;
     sg.d1 = (long long)sg.d0 + left < dm.D ? sg.d0 + (int)left : dm.D;
@@ -732,10 +732,6 @@ __global__ __launch_bounds__(256) void costvol_bwd_kernel(const io_t *__restrict
 #ifndef MD_COSTVOL_NWG
 #define MD_COSTVOL_NWG 0            // > 0: forward grid size (workgroups) instead of the occupancy-derived one
 #endif
-#ifndef MD_COSTVOL_FWD_SPLIT_NUM
-#define MD_COSTVOL_FWD_SPLIT_NUM 0   // forward, two slices per item: first slice = D * NUM / DEN steps (0: equal halves)
-#define MD_COSTVOL_FWD_SPLIT_DEN 1
-#endif
 #ifndef MD_COSTVOL_NWG_BWD
 #define MD_COSTVOL_NWG_BWD 0
 #endif
@@ -786,6 +782,10 @@ struct CvPtrs {
     float *d_ref, *d_src;
     unsigned flags;               // backward: MD_CV_* bits of the entry point
     unsigned long long *census;   // backward: (gathered steps << 32 | steps) of this launch, or null
+    const long long *shares;      // backward: caller's partition (n_shares pairs) or null
+    int n_shares;
+    unsigned *cost;               // backward: per-item cycle counters or null
+    int *plan_out;                // md_costvol_bwd_plan: {items, workgroups} of the launch, nothing launched
 };
 
 #include "costvol_cl.inc"
@@ -796,7 +796,6 @@ template <bool BWD, int N, int LPP, int NW, bool FUSED, bool FCL>
 int launch_cl_inst(const CvPtrs &q, const CvDims &dm, hipStream_t stream) {
     CvDims dm2 = dm;
     dm2.k1 = dm2.nc = dm2.fsub = 0;
-    dm2.split = 0;
     const void *fn;   // (if constexpr: only the direction's own kernel is instantiated)
     if constexpr (BWD) fn = (const void *)cl_bwd_kernel<N, LPP, NW, FUSED, FCL>;
     else fn = (const void *)cl_fwd_kernel<N, LPP, NW, FUSED, FCL>;
@@ -848,25 +847,43 @@ int launch_cl_inst(const CvPtrs &q, const CvDims &dm, hipStream_t stream) {
             }
         }
     }
-#if MD_COSTVOL_FWD_SPLIT_NUM
-    // Experiment (round 6): two UNEVEN halves per item, all long halves first.  Equal halves start, stage and walk in lockstep: on
-    // every CU the two resident workgroups sit in their fixed phase (set-up + staging: memory round trips, no stores) at the same
-    // time and compete for the store path at the same time.
-    if (!BWD && dm2.k1 == 2 && dm2.fsub == 1 && nwg == 2 * (long long)dm.items) {
-        int sp = (int)((long long)dm.D * MD_COSTVOL_FWD_SPLIT_NUM / MD_COSTVOL_FWD_SPLIT_DEN) & ~3;
-        if (sp >= 8 && dm.D - sp >= 8 && sp <= ITV_MAX) dm2.split = sp;
-    }
-#endif
     if (dm2.k1 > 0 && (dm.D + dm2.k1 - 1) / dm2.k1 > ITV_MAX) dm2.k1 = 0;  // an item-aligned slice (up to ceil(D / k) steps) must fit the interval table: plain shares
     if (nwg > total) { nwg = total; dm2.k1 = 0; }
     if (nwg * ITV_MAX < total) { nwg = (total + ITV_MAX - 1) / ITV_MAX; dm2.k1 = 0; }  // a share fits the interval table
+    if (q.plan_out) {   // md_costvol_bwd_plan: the launch geometry, nothing launched
+        q.plan_out[0] = dm.items;
+        q.plan_out[1] = (int)nwg;
+        return MD_OK;
+    }
+    dm2.shares = nullptr;
+    dm2.cost = nullptr;
+    bool cost_cleared_census = false;
+    if constexpr (BWD) {
+        // The caller's partition of the items x D steps (round 6): one [lo, hi) pair per workgroup, from the per-item cycle counts
+        // (`cost`) of an earlier launch on similar poses -- all workgroups of this kernel are resident at once, so no hardware
+        // scheduler evens out what parallax makes uneven (workgroup lifetimes max / mean 1.4-1.5 on the driving-scene and moderate
+        // cases: the launch lasts as long as its slowest tile).  A share may span items (next_segment cuts it at item boundaries).
+        if (q.shares) {
+            MD_REQUIRE(q.n_shares > 0 && dm.D <= ITV_MAX, "md_costvol_bwd: shares need n_shares > 0 and D <= %d", ITV_MAX);
+            nwg = q.n_shares;
+            dm2.k1 = dm2.nc = dm2.fsub = 0;
+            dm2.shares = q.shares;
+        }
+        if (q.cost) {
+            // (census word directly in front of the counters, as ops.BackwardPolicy lays them out: one fill for both)
+            const bool adj = q.census && (char *)q.census + sizeof(unsigned long long) == (char *)q.cost;
+            MD_CHECK_HIP(hipMemsetAsync(adj ? (void *)q.census : (void *)q.cost, 0, sizeof(unsigned) * (size_t)dm.items + (adj ? sizeof(unsigned long long) : 0), stream));
+            dm2.cost = q.cost;
+            cost_cleared_census = adj;
+        }
+    }
     const dim3 grid((unsigned)nwg), block(64 * NW);
     const char *tname = BWD ? MD_CV_STR(MD_CV_NAME(md_costvol_bwd)) : MD_CV_STR(MD_CV_NAME(md_costvol_fwd));
     if (BWD) {
         // d_src is accumulated with atomics from every workgroup whose window covers a cell: zero it.  d_ref is STORED when a
         // segment is the pixel's only contributor -- true for every segment when each item is one whole-D slice and no other
         // launch shares the samples -- so it only needs the fill otherwise (config 2: 720 items on 768 slots, k = 1).
-        const bool whole = dm2.k1 == 1 && dm2.fsub == 1 && nwg == dm.items && !MD_CL_DREF_ATOMIC;
+        const bool whole = dm2.k1 == 1 && dm2.fsub == 1 && nwg == dm.items && !MD_CL_DREF_ATOMIC && !dm2.shares;
         const size_t bytes = sizeof(float) * (size_t)dm.B * dm.C * dm.h * dm.w;
         if (!whole && (char *)q.d_ref + bytes == (char *)q.d_src) {
             MD_CHECK_HIP(hipMemsetAsync(q.d_ref, 0, 2 * bytes, stream));
@@ -875,7 +892,7 @@ int launch_cl_inst(const CvPtrs &q, const CvDims &dm, hipStream_t stream) {
             if (!whole) MD_CHECK_HIP(hipMemsetAsync(q.d_ref, 0, bytes, stream));
         }
     }
-    if (BWD && q.census) MD_CHECK_HIP(hipMemsetAsync(q.census, 0, sizeof(unsigned long long), stream));
+    if (BWD && q.census && !cost_cleared_census) MD_CHECK_HIP(hipMemsetAsync(q.census, 0, sizeof(unsigned long long), stream));
     dm2.census = BWD ? q.census : nullptr;
     hipEvent_t ev0, ev1;
     md_timing_pair(tname, &ev0, &ev1);
@@ -969,6 +986,11 @@ int launch(const CvPtrs &q, CvDims dm, hipStream_t stream) {
     dm.min_sub = BWD ? MD_COSTVOL_MIN_SUB_BWD : MD_COSTVOL_MIN_SUB;
     if (dm.min_sub < 4) dm.min_sub = 4;
     if (cl_eligible(dm, BWD ? (const void *)q.gout : (const void *)q.out)) return launch_cl<BWD>(q, dm, stream);
+    if (q.plan_out) { q.plan_out[0] = q.plan_out[1] = 0; return MD_OK; }   // (no caller-side partition for the planar-era kernels)
+    if (BWD && (q.shares || q.cost)) {
+        md_set_error("md_costvol_bwd: shares / cost are taken by the channels-last-volume kernels only");
+        return MD_EINVAL;
+    }
     if (dm.fcl) {
         md_set_error("costvol: channels-last feature maps need the channels-last volume kernels (volume (B,D,h,w,G) with G = 8 or 16, "
                      "C/G = 1, 2 or 4, 16-byte aligned): got C=%d G=%d strides (%lld,%lld,%lld,%lld)", dm.C, dm.G, dm.sb, dm.sd, dm.sg, dm.sp);
@@ -1150,7 +1172,8 @@ extern "C" int MD_CV_NAME(md_costvol_bwd)(const abi_io_t *gout_, long long g_sb,
                               const abi_io_t *src_, const float *K, const float *invK, const float *pose,
                               const float *hyp, const float *prior, const float *ztrans, float scale_fac,
                               int sched_type, int B, int C, int G, int h, int w, int D, int feat_cl, float *d_ref,
-                              float *d_src, unsigned flags, unsigned long long *census, md_stream_t stream) {
+                              float *d_src, unsigned flags, unsigned long long *census, const long long *shares, int n_shares,
+                              unsigned *cost, md_stream_t stream) {
     const io_t *gout = reinterpret_cast<const io_t *>(gout_), *ref = reinterpret_cast<const io_t *>(ref_),
                *src = reinterpret_cast<const io_t *>(src_);
     int rc = check_common("md_costvol_bwd", ref, src, K, invK, pose, hyp, prior, sched_type, B, C, G, h, w, D);
@@ -1159,7 +1182,9 @@ extern "C" int MD_CV_NAME(md_costvol_bwd)(const abi_io_t *gout_, long long g_sb,
     MD_REQUIRE((flags & ~(unsigned)MD_CV_GATHER_TABLE) == 0, "md_costvol_bwd: unknown flag bits 0x%x", flags);
     MD_REQUIRE(((uintptr_t)census % 8) == 0, "md_costvol_bwd: census must be 8-byte aligned");
     CvPtrs q{};
+    MD_REQUIRE(((uintptr_t)shares % 8) == 0 && ((uintptr_t)cost % 4) == 0 && n_shares >= 0, "md_costvol_bwd: misaligned shares / cost");
     q.flags = flags; q.census = census;
+    q.shares = n_shares > 0 ? shares : nullptr; q.n_shares = n_shares; q.cost = cost;
     q.gout = gout; q.ref = ref; q.src = src; q.K = K; q.invK = invK; q.pose = pose; q.hyp = hyp; q.prior = prior;
     q.ztrans = ztrans; q.d_ref = d_ref; q.d_src = d_src;
     CvDims dm{};
@@ -1171,3 +1196,21 @@ extern "C" int MD_CV_NAME(md_costvol_bwd)(const abi_io_t *gout_, long long g_sb,
     // them; none for d_ref when the launch stores it)
     return launch<true>(q, dm, (hipStream_t)stream);
 }
+
+#if MD_CV_IO == 0
+extern "C" int md_costvol_bwd_plan(int B, int C, int G, int h, int w, int D, int feat_cl, int *items, int *workgroups) {
+    MD_REQUIRE(items && workgroups, "md_costvol_bwd_plan: null output");
+    MD_REQUIRE(B > 0 && C > 0 && G > 0 && C % G == 0 && h > 1 && w > 1 && D > 0, "md_costvol_bwd_plan: bad dims");
+    CvPtrs q{};
+    int out[2] = {0, 0};
+    q.plan_out = out;
+    CvDims dm{};
+    dm.B = B; dm.C = C; dm.G = G; dm.h = h; dm.w = w; dm.D = D;
+    dm.sg = 1; dm.sp = G; dm.sd = (long long)h * w * G; dm.sb = (long long)D * h * w * G;   // the channels-last volume (B,D,h,w,G)
+    dm.fcl = feat_cl != 0;
+    const int rc = launch<true>(q, dm, nullptr);
+    *items = out[0];
+    *workgroups = out[1];
+    return rc;
+}
+#endif

@@ -158,49 +158,154 @@ def _is_cl(t):
     return t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last) and not t.is_contiguous()
 
 
-class GatherTablePolicy:
-    """Chooses md_costvol_bwd's MD_CV_GATHER_TABLE flag per launch, without a host synchronisation and without anything read from
-    the environment.  Every backward launch leaves its census -- (hypothesis steps walked in gather mode << 32) | all steps -- in a
-    device word; an asynchronous copy brings it to pinned host memory behind the launch, and the NEXT launch reads whatever census
-    has landed by then (this step's earlier volume or the previous step's: poses drift over hundreds of steps, the untrained-pose
-    phase the table kernel exists for lasts that long).  Above `threshold` of the steps gathered (wild poses: ~65 % at config 2's
-    shape; moderate ~27 %, driving scene < 1 %, sane 0: profiles/r05_costvol_wgstats.txt) the cell-table build pays
-    (csrc/costvol.hip launch_cl_inst).  `force` = True / False pins the choice (tests, A/B runs)."""
+class BackwardPolicy:
+    """Per-launch choices of md_costvol_bwd* that depend on the POSES, made on the host without a synchronisation and without anything
+    read from the environment (ABI 17: `flags`, `census`, `shares`, `cost`).  Every backward launch leaves, in one small device
+    buffer, its census -- (hypothesis steps walked in gather mode << 32) | all steps -- and the shader cycles it spent per work item
+    (16 x 4-pixel tile of one sample); an asynchronous copy brings both to pinned host memory behind the launch, and the NEXT launch
+    of the same shape reads whatever has landed by then (this step's earlier volume or the previous step's: poses and depths drift
+    over hundreds of steps).  From them:
+      * MD_CV_GATHER_TABLE when more than `threshold` of the steps were gathered (wild poses of an untrained pose network: ~65 % at
+        config 2's shape; moderate ~27 %, driving scene < 1 %, sane 0): the cell-table build pays only there;
+      * a partition of the launch's work with equal COST per workgroup instead of equal steps when the items' costs are very uneven
+        (max / mean above `imbalance`) and next to nothing is gathered: all workgroups of the backward are resident at once, so
+        nothing else evens out what parallax makes uneven -- a driving-scene launch lasts as long as its slowest tile
+        (csrc/costvol.hip launch_cl_inst; 107.9 -> 98.4 us at 1 m per frame, profiles/r06_costvol_spec.txt).  The measure is noisy --
+        equal tiles differ by 1.5-1.8x in cycles with where they ran -- so the bar is high (2.2; sane launches stay on the library's
+        own partition, d_ref stored without a fill), and launches with gathered sub-slices are left alone: their tail is the chip's
+        atomic rate, which no partition changes (moderate poses: 122.9 -> 142.8 us balanced).
+    `force_table` / `force_balance` = True / False pin a choice (tests, A/B runs)."""
 
-    def __init__(self, device, threshold=0.45):
-        self.dev = torch.zeros(1, dtype=torch.int64, device=device)
-        self.host = torch.zeros(1, dtype=torch.int64).pin_memory()
-        self.threshold = float(threshold)
-        self.force = None
-        self.launches = self.table_launches = 0
+    RING = 4   # pinned upload buffers per shape: one is rewritten only after its copy has completed (event), else the launch goes unbalanced
 
-    def gathered_share(self):
+    def __init__(self, device, threshold=0.45, imbalance=2.2, max_gathered_for_balance=0.05):
+        self.device = device
+        self.threshold, self.imbalance, self.max_gathered = float(threshold), float(imbalance), float(max_gathered_for_balance)
+        self.force_table = self.force_balance = None
+        self.launches = self.table_launches = self.balanced_launches = 0
+        self._shapes = {}
+        self._last = None
+
+    # -- per-shape state
+    def _state(self, key):
+        st = self._shapes.get(key)
+        if st is None:
+            import ctypes as C
+            B, Cc, G, h, w, D, fcl, cl_volume = key
+            items, nwg = C.c_int(0), C.c_int(0)
+            if cl_volume:
+                _lib.call("md_costvol_bwd_plan", B, Cc, G, h, w, D, int(fcl), C.byref(items), C.byref(nwg))
+            st = type("S", (), {})()
+            st.items, st.nwg, st.D = items.value, nwg.value, D
+            n = max(st.items, 1)
+            st.dev = torch.zeros(2 + n, dtype=torch.int32, device=self.device)       # [census lo, census hi, cost per item ...]
+            st.host = torch.zeros(2 + n, dtype=torch.int32).pin_memory()
+            st.shares_dev = torch.zeros(max(st.nwg, 1), 2, dtype=torch.int64, device=self.device)
+            st.ring = [(torch.zeros(max(st.nwg, 1), 2, dtype=torch.int64).pin_memory(), torch.cuda.Event()) for _ in range(self.RING)]
+            st.ring_used = [False] * self.RING
+            st.slot = 0
+            self._shapes[key] = st
+        return st
+
+    @staticmethod
+    def _census(host):
+        lo, hi = int(host[0]) & 0xFFFFFFFF, int(host[1]) & 0xFFFFFFFF     # little-endian halves of the 64-bit word
+        return hi, lo                                                      # gathered steps, all steps
+
+    def gathered_share(self, key=None):
         """Share of the last landed census' hypothesis steps that ran in gather mode (plain read of pinned memory: never waits)."""
-        v = int(self.host[0])
-        g, t = (v >> 32) & 0xFFFFFFFF, v & 0xFFFFFFFF
+        st = self._shapes.get(key) if key is not None else self._last
+        if st is None:
+            return 0.0
+        g, t = self._census(st.host)
         return g / t if t else 0.0
 
-    def flags(self):
-        on = self.force if self.force is not None else self.gathered_share() > self.threshold
+    def costs(self, key=None):
+        """Per-item shader cycles of the last landed launch (numpy view of pinned memory)."""
+        st = self._shapes.get(key) if key is not None else self._last
+        return None if st is None or st.items == 0 else st.host[2:2 + st.items].numpy()
+
+    def partition(self, cost, nwg, D, quantum=8):
+        """[lo, hi) per workgroup in step units (item * D + d): equal cost per workgroup, boundaries on multiples of `quantum` steps
+        inside an item (a sub-slice shorter than that is all fixed cost)."""
+        import numpy as np
+        c = np.maximum(cost.astype(np.float64), 1.0)
+        acc = np.concatenate([[0.0], np.cumsum(c)])
+        x = acc[-1] * np.arange(nwg + 1, dtype=np.float64) / nwg
+        i = np.clip(np.searchsorted(acc, x, side="right") - 1, 0, len(c) - 1)
+        step = i * D + np.minimum(np.round((x - acc[i]) / c[i] * D / quantum) * quantum, D).astype(np.int64)
+        step[0], step[-1] = 0, len(c) * D
+        step = np.maximum.accumulate(step)
+        return np.stack([step[:-1], step[1:]], 1)
+
+    def before_launch(self, key):
+        """-> (flags, census pointer, shares pointer, n_shares, cost pointer) for the launch about to be made on the current stream"""
+        st = self._last = self._state(key)
         self.launches += 1
-        self.table_launches += int(bool(on))
-        return _lib.CV_GATHER_TABLE if on else 0
+        table = self.force_table if self.force_table is not None else self.gathered_share(key) > self.threshold
+        self.table_launches += int(bool(table))
+        flags = _lib.CV_GATHER_TABLE if table else 0
+        base = st.dev.data_ptr()
+        if st.items == 0:
+            return flags, base, None, 0, None
+        shares, n = None, 0
+        cost = st.host[2:2 + st.items].numpy()
+        want = self.force_balance
+        if want is None:
+            tot = float(cost.sum())
+            want = tot > 0 and float(cost.max()) * st.items > self.imbalance * tot and self.gathered_share(key) < self.max_gathered
+        if want and float(cost.sum()) > 0:
+            buf, ev = st.ring[st.slot]
+            if not st.ring_used[st.slot] or ev.query():     # (never waits: a busy slot means this launch goes unbalanced)
+                buf.numpy()[:] = self.partition(cost, st.nwg, st.D)
+                st.shares_dev.copy_(buf, non_blocking=True)
+                ev.record()
+                st.ring_used[st.slot] = True
+                st.slot = (st.slot + 1) % self.RING
+                shares, n = st.shares_dev.data_ptr(), st.nwg
+                self.balanced_launches += 1
+        return flags, base, shares, n, base + 8
 
-    def after_launch(self):
-        self.host.copy_(self.dev, non_blocking=True)   # stream-ordered behind the launch; the host does not wait for it
+    def after_launch(self, key):
+        st = self._shapes[key]
+        st.host.copy_(st.dev, non_blocking=True)   # stream-ordered behind the launch; the host does not wait for it
+
+    def last_census(self):
+        """(gathered steps, all steps) of the most recent launch, read from the DEVICE (synchronises: tests and tools only)."""
+        return self._census(self._last.dev[:2].cpu())
+
+    def reset(self):
+        """forget every shape's history (tests)"""
+        torch.cuda.synchronize()
+        self._shapes.clear()
+        self._last = None
+        self.force_table = self.force_balance = None
+
+    # round-6 name of the first half of this object (tests, tools)
+    @property
+    def force(self):
+        return self.force_table
+
+    @force.setter
+    def force(self, v):
+        self.force_table = v
 
 
-_GATHER_POLICIES = {}
+GatherTablePolicy = BackwardPolicy
+_BACKWARD_POLICIES = {}
 
 
-def gather_table_policy(device=None):
+def backward_policy(device=None):
     """The process' policy object of `device` (created on first use)."""
     idx = torch.cuda.current_device() if device is None else torch.device(device).index
     if idx is None:
         idx = torch.cuda.current_device()
-    if idx not in _GATHER_POLICIES:
-        _GATHER_POLICIES[idx] = GatherTablePolicy(torch.device("cuda", idx))
-    return _GATHER_POLICIES[idx]
+    if idx not in _BACKWARD_POLICIES:
+        _BACKWARD_POLICIES[idx] = BackwardPolicy(torch.device("cuda", idx))
+    return _BACKWARD_POLICIES[idx]
+
+
+gather_table_policy = backward_policy
 
 
 class _CostVolume(torch.autograd.Function):
@@ -252,12 +357,14 @@ class _CostVolume(torch.autograd.Function):
         else:
             d_both = torch.empty((2,) + tuple(ref.shape), device=ref.device, dtype=torch.float32)
         d_ref, d_src = d_both[0], d_both[1]
-        pol = gather_table_policy(ref.device)
+        pol = backward_policy(ref.device)
+        key = (B, C, G, h, w, D, bool(ctx.fcl), layout == "ndhwc")   # (other volume layouts: census only, the library's own partition)
+        flags, census, shares, n_shares, cost = pol.before_launch(key)
         _timed_call("md_costvol_bwd" + ctx.sfx, _p(g), sb, sd, sg, sp, _p(ref), _p(src), _p(K), _p(invK), _p(pose),
                     _p(hyp if has_hyp else None), _p(prior if has_prior else None), _p(ztrans if has_z else None),
-                    scale_fac, sched_type, B, C, G, h, w, D, int(ctx.fcl), _p(d_ref), _p(d_src), pol.flags(), _p(pol.dev),
+                    scale_fac, sched_type, B, C, G, h, w, D, int(ctx.fcl), _p(d_ref), _p(d_src), flags, census, shares, n_shares, cost,
                     _stream())
-        pol.after_launch()
+        pol.after_launch(key)
         return (d_ref.to(ctx.io), d_src.to(ctx.io)) + (None,) * 11
 
 

@@ -470,14 +470,16 @@ def test_costvol_wild_poses_backward_fallback_vs_oracle(ops, oracle_lib, feat):
     finally:
         ops.enable_library_kernel_timing(False)
     assert t["md_costvol_bwd"]["launches"] == 1, t
-    pol = ops.gather_table_policy()
+    pol = ops.backward_policy()
     torch.cuda.synchronize()
-    v = int(pol.dev.item())
-    assert (v & 0xFFFFFFFF) == B * (h // 4) * (w // 16) * D, hex(v)     # every hypothesis step of every 16 x 4 tile, once
+    gathered, total = pol.last_census()
+    assert total == B * (h // 4) * (w // 16) * D, (gathered, total)      # every hypothesis step of every 16 x 4 tile, once
     if feat == "nhwc":
         assert 0.1 < pol.gathered_share() < 0.9, pol.gathered_share()   # two of three samples wild (D = 32: short slices fit more often)
+        c = pol.costs()
+        assert c is not None and len(c) == B * (h // 4) * (w // 16) and (c > 0).all()   # per-item cycle counts of the launch
     else:
-        assert (v >> 32) == 0                                            # planar features never gather
+        assert gathered == 0                                             # planar features never gather
     assert_close(host(r.grad), exp_dref, what="d_ref")
     assert_close(host(s.grad), exp_dsrc, what="d_src")
 
@@ -503,8 +505,9 @@ def test_costvol_backward_cell_table_vs_oracle(ops, oracle_lib, case):
     hyp = oracle_lib.schedule_depth_range(prior, D, 0.3, None, "inverse")
     gout = rng.standard_normal((B, D, G, h, w)).astype(np.float32)
     exp_dref, exp_dsrc = oracle_lib.costvol_grouped_bwd(gout, ref, src, K, invK, hyp, pose)
-    pol = ops.gather_table_policy()
-    pol.force = True
+    pol = ops.backward_policy()
+    pol.reset()
+    pol.force_table = True
     ops.enable_library_kernel_timing(True)
     try:
         r, s = feat_dev(ref, "nhwc"), feat_dev(src, "nhwc")
@@ -515,7 +518,7 @@ def test_costvol_backward_cell_table_vs_oracle(ops, oracle_lib, case):
         t = ops.library_kernel_times_us(["md_costvol_bwd"])
     finally:
         ops.enable_library_kernel_timing(False)
-        pol.force = None
+        pol.force_table = None
     assert t["md_costvol_bwd"]["launches"] == 1, t
     assert_close(host(r.grad), exp_dref, what="d_ref")
     assert_close(host(s.grad), exp_dsrc, what="d_src")
@@ -537,10 +540,10 @@ def test_costvol_gather_table_policy_follows_the_poses(ops, oracle_lib):
     gout = rng.standard_normal((B, D, G, h, w)).astype(np.float32)
     poses = {"wild": rand_pose(oracle_lib, rng, B, 0.3, 2.0), "sane": rand_pose(oracle_lib, rng, B, 0.01, 0.05)}
     exp = {k: oracle_lib.costvol_grouped_bwd(gout, ref, src, K, invK, hyp, p) for k, p in poses.items()}
-    pol = ops.gather_table_policy()
-    pol.force = None
-    torch.cuda.synchronize()
-    pol.host.zero_()
+    pol = ops.backward_policy()
+    pol.reset()
+    pol.force_balance = False      # (the partition is test_costvol_backward_balanced_partition_vs_oracle's subject)
+    keep_threshold, pol.threshold = pol.threshold, 0.15   # B = 2: three 32-step slices per item fit their windows more often than config 2's whole-depth slices
     seen = []
     for case in ("wild", "wild", "sane", "sane"):
         r, s = feat_dev(ref, "nhwc"), feat_dev(src, "nhwc")
@@ -552,7 +555,64 @@ def test_costvol_gather_table_policy_follows_the_poses(ops, oracle_lib):
         print("gather-table policy: %s poses, gathered share %.3f, table build used: %d" % (case, pol.gathered_share(), seen[-1]))
         assert_close(host(r.grad), exp[case][0], what="d_ref " + case)
         assert_close(host(s.grad), exp[case][1], what="d_src " + case)
+    pol.threshold = keep_threshold
+    pol.reset()
     assert seen == [0, 1, 1, 0], seen
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("case", ["driving_2m", "moderate", "wild"])
+def test_costvol_backward_balanced_partition_vs_oracle(ops, oracle_lib, case, dtype):
+    """md_costvol_bwd's `shares` / `cost` (ABI 17; ops.BackwardPolicy): the first launch records the shader cycles per work item, the
+    second runs on the partition the policy computes from them -- equal COST per workgroup, shares that cut items at multiples of 8
+    steps and span item boundaries, d_ref accumulated with atomics -- at config 2's launch shape on the cases whose tiles differ in
+    cost (driving scene, moderate poses; wild poses: together with the cell table).  Checked: the partition covers every step exactly
+    once, both launches' gradients against the oracle (autograd of layers.py:784-792), white-noise features and gradient."""
+    from movedepth_amd.synthetic import driving_scene
+    rng = np.random.default_rng(85)
+    B, C, G, h, w, D = 6, 32, 16, 48, 160, 96
+    half = dtype != torch.float32
+    rnd = (lambda a: torch.from_numpy(a).to(dtype).float().numpy()) if half else (lambda a: a)
+    ref = rnd(rng.standard_normal((B, C, h, w)).astype(np.float32))
+    src = rnd(rng.standard_normal((B, C, h, w)).astype(np.float32))
+    K, invK = kitti_K(h, w, B)
+    if case == "driving_2m":
+        prior, pose = driving_scene(B, h, w, speed=2.0)
+    else:
+        prior = (2 + 20 * smooth_field(rng, (B, 1, h, w), 12, 0, 1)).astype(np.float32)
+        pose = rand_pose(oracle_lib, rng, B, 0.3, 2.0) if case == "wild" else rand_pose(oracle_lib, rng, B, 0.05, 0.3)
+    hyp = oracle_lib.schedule_depth_range(prior, D, 0.3, None, "inverse")
+    gout = rnd(rng.standard_normal((B, D, G, h, w)).astype(np.float32))
+    exp_dref, exp_dsrc = oracle_lib.costvol_grouped_bwd(gout, ref, src, K, invK, hyp, pose)
+    tol = 5e-4 if half else 1e-4
+    pol = ops.backward_policy()
+    pol.reset()
+    key = (B, C, G, h, w, D, True, True)
+    try:
+        for launch in range(3):
+            pol.force_balance = launch > 0
+            r, s = feat_dev(ref, "nhwc", dtype=dtype), feat_dev(src, "nhwc", dtype=dtype)
+            vol = ops.costvol_grouped(r, s, dev(K), dev(invK), dev(pose), G, prior=dev(prior), ndepth=D, scale_fac=0.3, type="inverse",
+                                      layout="ndhwc")
+            before = pol.balanced_launches
+            vol.backward(torch.from_numpy(gout).to(dtype).cuda())
+            torch.cuda.synchronize()
+            assert pol.balanced_launches - before == int(launch > 0)
+            e_r, e_s = relerr(host(r.grad), exp_dref), relerr(host(s.grad), exp_dsrc)
+            cost = pol.costs(key).astype(np.float64)
+            print("%s %s launch %d (%s): d_ref %.2e d_src %.2e; item cycles max / mean %.2f" % (
+                case, dtype, launch, "balanced" if launch else "library partition", e_r, e_s, cost.max() / cost.mean()))
+            assert e_r <= tol and e_s <= tol, (launch, e_r, e_s)
+            assert (cost > 0).all()
+            if launch > 0:
+                sh = pol._shapes[key].shares_dev.cpu().numpy()
+                assert sh[0, 0] == 0 and sh[-1, 1] == B * (h // 4) * (w // 16) * D
+                assert (sh[1:, 0] == sh[:-1, 1]).all() and (sh[:, 1] >= sh[:, 0]).all()      # contiguous, ordered: every step exactly once
+                assert ((sh % D) % 8 == 0).all()
+                lens = sh[:, 1] - sh[:, 0]
+                assert lens.max() > lens[lens > 0].min()                                       # it IS uneven in steps
+    finally:
+        pol.reset()
 
 
 @pytest.mark.parametrize("feat", FEATS)

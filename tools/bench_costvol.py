@@ -81,6 +81,14 @@ def main():
     vol = ops.costvol_grouped(ref, src, K, invK, pose, G, layout=a.layout, **kw)
     g = torch.randn_like(vol)
 
+    # the backward's per-launch policy (ops.BackwardPolicy): BAL / TABLE = 0 | 1 pin the cost-balanced partition / the cell-table build,
+    # unset: the automatic choice from the previous launch's census and per-item costs
+    pol = ops.backward_policy()
+    pol.reset()
+    for envname, attr in (("BAL", "force_balance"), ("TABLE", "force_table")):
+        if os.environ.get(envname) in ("0", "1"):
+            setattr(pol, attr, os.environ[envname] == "1")
+
     keep = [None] * max(a.rotate - 1, 0)
     cnt = [0]
 
@@ -121,7 +129,11 @@ def main():
     sfx = {"f32": "", "bf16": "_bf16", "f16": "_f16"}[a.dtype]
     lib_t = ops.library_kernel_times_us(["md_costvol_fwd" + sfx, "md_costvol_bwd" + sfx])
     ops.enable_library_kernel_timing(False)
-    env = {k: v for k, v in os.environ.items() if k.startswith("MD_")}
+    env = {k: v for k, v in os.environ.items() if k.startswith("MD_") or k in ("BAL", "TABLE")}
+    cst = pol.costs()
+    if cst is not None and cst.sum() > 0:
+        print("  backward policy: %d launches, %d on the cell-table build, %d on a cost-balanced partition; gathered share %.3f; item cycles max / mean %.2f" % (
+            pol.launches, pol.table_launches, pol.balanced_launches, pol.gathered_share(), float(cst.max()) * len(cst) / float(cst.sum())))
     print("costvol B=%d %dx%d D=%d C=%d G=%d fused=%d layout=%s feat=%s dtype=%s prior=%s env=%s" % (B, h, w, D, C, G, a.fused, a.layout, a.feat, a.dtype, a.prior, env))
     print("  fwd %8.1f us  %7.1f MB  %7.0f GB/s (%.1f%% of 8 TB/s)" % (tf, fbytes / 1e6, fbytes / tf / 1e3, fbytes / tf / 1e3 / 80))
     print("  bwd %8.1f us  %7.1f MB  %7.0f GB/s (%.1f%% of 8 TB/s)  [includes 2 memsets + autograd glue]" % (tb, bbytes / 1e6, bbytes / tb / 1e3, bbytes / tb / 1e3 / 80))

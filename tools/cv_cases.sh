@@ -27,11 +27,11 @@ for lib in "${@:-}"; do
   echo "#### library: ${lib:-in-tree}"
   for dt in $DTYPES; do for c in $CASES; do
     echo "== $dt $c"
-    run_case $c --dtype $dt ${STATS:+} 2>&1 | grep "kernel only\|stats " | sed 's/(dispatch start.stop events inside the library) //'
+    run_case $c --dtype $dt 2>&1 | grep "kernel only\|stats \|backward policy" | sed 's/(dispatch start.stop events inside the library) //'
   done; done
   if [ -z "$NO_CFG4" ]; then for c in sane kitti1; do
     echo "== cfg4 bf16 $c"
-    run_case $c --B 6 --h 80 --w 256 --D 128 --dtype bf16 2>&1 | grep "kernel only" | sed 's/(dispatch start.stop events inside the library) //'
+    run_case $c --B 6 --h 80 --w 256 --D 128 --dtype bf16 2>&1 | grep "kernel only\|backward policy" | sed 's/(dispatch start.stop events inside the library) //'
   done; fi
 done
 } > $O/cases.txt 2>&1
