@@ -63,11 +63,16 @@ int md_schedule_depth_range(const float *prior, const float *ztrans, int B, int 
  *   feat_cl != 0: ref and src (and d_ref, d_src of the backward) are channels-last [B,h,w,C] -- what the 2-D encoder
  *   (resnet_encoder.py:360,387 FPN4) produces when it runs in torch.channels_last -- instead of [B,C,h,w]; taken by the
  *   channels-last-volume kernels only (sg = 1, sp = G, G = 8 or 16, C/G = 1, 2 or 4), MD_EINVAL otherwise.
+ *   flags (ABI 17): MD_CV_FINE_SLICES = twice the hypothesis slices per work item (channels-last kernels): evens out launches
+ *   whose tiles differ in cost (parallax: moderate poses 66 -> 62 us, driving scene 64.8 -> 61.5 at B=6, 48x160, D=96) at the
+ *   price of a second window staging per item when they do not (58 -> 59.1 us); same results.  The caller's choice
+ *   (movedepth_amd/ops.py BackwardPolicy: from the previous backward's census); unknown bits are MD_EINVAL.
  */
+#define MD_CV_FINE_SLICES 2u
 int md_costvol_fwd(const float *ref, const float *src, const float *K, const float *invK, const float *pose,
                    const float *hyp, const float *prior, const float *ztrans, float scale_fac, int sched_type,
                    int B, int C, int G, int h, int w, int D, int feat_cl, float *out, long long out_sb, long long out_sd,
-                   long long out_sg, long long out_sp, md_stream_t stream);
+                   long long out_sg, long long out_sp, unsigned flags, md_stream_t stream);
 
 /* Autograd of md_costvol_fwd w.r.t. ref and src (the sampling grid is under no_grad, layers.py:784).
  * gout addressed with the same four strides; d_ref, d_src [B,C,h,w] ([B,h,w,C] with feat_cl) are overwritten (d_src is
@@ -80,10 +85,10 @@ int md_costvol_fwd(const float *ref, const float *src, const float *K, const flo
  *   flags (ABI 17; the library reads nothing from the process environment): MD_CV_GATHER_TABLE selects the build of the
  *   16 x 4-tile kernel that also merges those terms per source cell in LDS before they leave the CU: for phases with wild
  *   poses (5.1x instead of 8.7x the sane time), ~7 % slower when poses are sane; same results to float-atomic ordering.
- *   census (ABI 17; may be NULL): one device word, 8-byte aligned, overwritten by this launch with
- *   (hypothesis steps walked in gather mode << 32) | (all hypothesis steps walked) -- what a caller decides the flag of its NEXT
- *   launch from without a host synchronisation (an asynchronous copy to pinned memory read one call later; movedepth_amd/ops.py
- *   GatherTablePolicy does exactly that).
+ *   census (ABI 17; may be NULL): one device word, 8-byte aligned, overwritten by this launch with four counts --
+ *   [63:46] hypothesis steps walked in gather mode / 4, [45:28] all hypothesis steps walked / 4, [27:14] windows staged,
+ *   [13:0] segments (meaningful below 2^20 steps and 2^14 segments per launch) -- what a caller decides the flags of its NEXT launches from without
+ *   a host synchronisation (an asynchronous copy to pinned memory read one call later; movedepth_amd/ops.py BackwardPolicy).
  *   shares, n_shares, cost (ABI 17; NULL / 0 / NULL: the library's own equal partition, nothing recorded; taken by the
  *   channels-last-volume kernels only): every workgroup of the backward is resident at once, so no hardware scheduler evens out
  *   what parallax makes uneven -- the launch lasts as long as its slowest tile (workgroup lifetimes max / mean 1.4-1.5 on driving
@@ -112,7 +117,7 @@ int md_costvol_bwd(const float *gout, long long g_sb, long long g_sd, long long 
 int md_costvol_fwd_bf16(const uint16_t *ref, const uint16_t *src, const float *K, const float *invK, const float *pose,
                         const float *hyp, const float *prior, const float *ztrans, float scale_fac, int sched_type, int B,
                         int C, int G, int h, int w, int D, int feat_cl, uint16_t *out, long long out_sb, long long out_sd,
-                        long long out_sg, long long out_sp, md_stream_t stream);
+                        long long out_sg, long long out_sp, unsigned flags, md_stream_t stream);
 int md_costvol_bwd_bf16(const uint16_t *gout, long long g_sb, long long g_sd, long long g_sg, long long g_sp,
                         const uint16_t *ref, const uint16_t *src, const float *K, const float *invK, const float *pose,
                         const float *hyp, const float *prior, const float *ztrans, float scale_fac, int sched_type, int B,
@@ -121,7 +126,7 @@ int md_costvol_bwd_bf16(const uint16_t *gout, long long g_sb, long long g_sd, lo
 int md_costvol_fwd_f16(const uint16_t *ref, const uint16_t *src, const float *K, const float *invK, const float *pose,
                        const float *hyp, const float *prior, const float *ztrans, float scale_fac, int sched_type, int B,
                        int C, int G, int h, int w, int D, int feat_cl, uint16_t *out, long long out_sb, long long out_sd,
-                       long long out_sg, long long out_sp, md_stream_t stream);
+                       long long out_sg, long long out_sp, unsigned flags, md_stream_t stream);
 int md_costvol_bwd_f16(const uint16_t *gout, long long g_sb, long long g_sd, long long g_sg, long long g_sp,
                        const uint16_t *ref, const uint16_t *src, const float *K, const float *invK, const float *pose,
                        const float *hyp, const float *prior, const float *ztrans, float scale_fac, int sched_type, int B,

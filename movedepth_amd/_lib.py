@@ -16,11 +16,12 @@ _ll = ctypes.c_longlong
 _sz = ctypes.c_size_t
 
 # md_costvol_fwd / _bwd (and their _bf16 / _f16 twins): ..., B, C, G, h, w, D, feat_cl, ...
-_CV_FWD = [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _ll, _ll, _ll, _ll, _vp]
+_CV_FWD = [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _ll, _ll, _ll, _ll, ctypes.c_uint, _vp]   # (ABI 17: ..., out strides, flags, stream)
 _u = ctypes.c_uint
 # (ABI 17: d_ref, d_src, flags, census, shares, n_shares, cost, stream)
 _CV_BWD = [_vp, _ll, _ll, _ll, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _u, _vp, _vp, _i, _vp, _vp]
-CV_GATHER_TABLE = 1   # MD_CV_GATHER_TABLE
+CV_GATHER_TABLE = 1   # MD_CV_GATHER_TABLE (md_costvol_bwd*)
+CV_FINE_SLICES = 2    # MD_CV_FINE_SLICES (md_costvol_fwd*)
 
 # name -> (restype, argtypes); must list every symbol the header declares (tests/test_cabi.py checks)
 SIGNATURES = {

@@ -101,7 +101,7 @@ struct CvDims {
     // slices each, workgroups >= nc take 1/fsub of one of the remaining slices (see launch_cl_inst)
     int k1, nc, fsub;
     unsigned long long *stats;   // md_costvol_stats: per-launch counters (null: off)
-    unsigned long long *census;  // backward: this launch's (hypothesis steps walked in gather mode << 32 | all steps), or null
+    unsigned long long *census;  // backward: this launch's census word (gathered steps / 4 and steps / 4: 18 bits each; windows staged, segments: 14 bits each), or null
     const long long *shares;     // backward: the caller's partition, [lo, hi) of the items x D steps per workgroup (null: the library's)
     unsigned *cost;              // backward: per item, the shader cycles the workgroups that walked it took (null: not recorded)
     int fcl;                     // feature maps and their gradients channels-last [B,h,w,C] (channels-last kernels only)
@@ -824,6 +824,12 @@ int launch_cl_inst(const CvPtrs &q, const CvDims &dm, hipStream_t stream) {
         // makes uneven: measured with 1440 instead of 720 workgroups at B=6, 48x160, D=96: moderate poses 72 -> 64 us, driving scene
         // 64 -> 62, but sane poses 59.4 -> 60.4, fp16 41 -> 48, config 4's shape 111 -> 126: a staging per slice is not free, and the
         // sane case is what a training step runs.  Not adopted; profiles/r05_costvol_parallax.txt.)
+        // MD_CV_FINE_SLICES (forward `flags`, round 6): twice the slices per item.  The hardware hands a free slot the next workgroup,
+        // which evens out what parallax makes uneven -- moderate poses 66 -> 62 us, driving scene 64.8 -> 61.5 at config 2's shape --
+        // and costs the sane case a second staging per item (58 -> 59.1 us; fp16 41 -> 48): the CALLER's choice, made by
+        // ops.BackwardPolicy from the previous backward's census (sub-slices staged per segment > 1: the tiles' sweeps outgrow
+        // their windows), fp32 only.
+        if (!BWD && (q.flags & MD_CV_FINE_SLICES)) k *= 2;
         if (k > dm.D / 8) k = dm.D / 8;
         if (k < 1) k = 1;
         nwg = (long long)dm.items * k;
@@ -997,7 +1003,7 @@ int launch(const CvPtrs &q, CvDims dm, hipStream_t stream) {
         return MD_EINVAL;
     }
     if (BWD) {   // first-generation backward: both gradients accumulate with atomics
-        if (q.census) MD_CHECK_HIP(hipMemsetAsync(q.census, 0, sizeof(unsigned long long), stream));   // (no gather mode in these kernels)
+        if (q.census) MD_CHECK_HIP(hipMemsetAsync(q.census, 0, sizeof(unsigned long long), stream));   // (no gather mode, no sub-slices in these kernels)
         const size_t bytes = sizeof(float) * (size_t)dm.B * dm.C * dm.h * dm.w;
         if ((char *)q.d_ref + bytes == (char *)q.d_src) {
             MD_CHECK_HIP(hipMemsetAsync(q.d_ref, 0, 2 * bytes, stream));
@@ -1150,13 +1156,15 @@ extern "C" int MD_CV_NAME(md_costvol_fwd)(const abi_io_t *ref_, const abi_io_t *
                               const float *pose, const float *hyp, const float *prior, const float *ztrans,
                               float scale_fac, int sched_type, int B, int C, int G, int h, int w, int D, int feat_cl,
                               abi_io_t *out_, long long out_sb, long long out_sd, long long out_sg, long long out_sp,
-                              md_stream_t stream) {
+                              unsigned flags, md_stream_t stream) {
     const io_t *ref = reinterpret_cast<const io_t *>(ref_), *src = reinterpret_cast<const io_t *>(src_);
     io_t *out = reinterpret_cast<io_t *>(out_);
     int rc = check_common("md_costvol_fwd", ref, src, K, invK, pose, hyp, prior, sched_type, B, C, G, h, w, D);
     if (rc) return rc;
     MD_REQUIRE(out, "md_costvol_fwd: null output");
+    MD_REQUIRE((flags & ~(unsigned)MD_CV_FINE_SLICES) == 0, "md_costvol_fwd: unknown flag bits 0x%x", flags);
     CvPtrs q{};
+    q.flags = flags;
     q.ref = ref; q.src = src; q.K = K; q.invK = invK; q.pose = pose; q.hyp = hyp; q.prior = prior; q.ztrans = ztrans;
     q.out = out;
     CvDims dm{};

@@ -161,7 +161,7 @@ def _is_cl(t):
 class BackwardPolicy:
     """Per-launch choices of md_costvol_bwd* that depend on the POSES, made on the host without a synchronisation and without anything
     read from the environment (ABI 17: `flags`, `census`, `shares`, `cost`).  Every backward launch leaves, in one small device
-    buffer, its census -- (hypothesis steps walked in gather mode << 32) | all steps -- and the shader cycles it spent per work item
+    buffer, its census -- steps walked in gather mode, all steps, windows staged, segments -- and the shader cycles it spent per work item
     (16 x 4-pixel tile of one sample); an asynchronous copy brings both to pinned host memory behind the launch, and the NEXT launch
     of the same shape reads whatever has landed by then (this step's earlier volume or the previous step's: poses and depths drift
     over hundreds of steps).  From them:
@@ -174,15 +174,18 @@ class BackwardPolicy:
         equal tiles differ by 1.5-1.8x in cycles with where they ran -- so the bar is high (2.2; sane launches stay on the library's
         own partition, d_ref stored without a fill), and launches with gathered sub-slices are left alone: their tail is the chip's
         atomic rate, which no partition changes (moderate poses: 122.9 -> 142.8 us balanced).
-    `force_table` / `force_balance` = True / False pin a choice (tests, A/B runs)."""
+      * MD_CV_FINE_SLICES for the FORWARD of the same shape (fp32) when the last backward staged more than `fine_above` windows per
+        segment or gathered anything: under parallax twice the slices per item even the forward out (moderate 66 -> 62 us).
+    `force_table` / `force_balance` / `force_fine` = True / False pin a choice (tests, A/B runs)."""
 
     RING = 4   # pinned upload buffers per shape: one is rewritten only after its copy has completed (event), else the launch goes unbalanced
 
     def __init__(self, device, threshold=0.45, imbalance=2.2, max_gathered_for_balance=0.05):
         self.device = device
         self.threshold, self.imbalance, self.max_gathered = float(threshold), float(imbalance), float(max_gathered_for_balance)
-        self.force_table = self.force_balance = None
-        self.launches = self.table_launches = self.balanced_launches = 0
+        self.force_table = self.force_balance = self.force_fine = None
+        self.fine_above = 1.005
+        self.launches = self.table_launches = self.balanced_launches = self.fine_launches = 0
         self._shapes = {}
         self._last = None
 
@@ -198,8 +201,12 @@ class BackwardPolicy:
             st = type("S", (), {})()
             st.items, st.nwg, st.D = items.value, nwg.value, D
             n = max(st.items, 1)
-            st.dev = torch.zeros(2 + n, dtype=torch.int32, device=self.device)       # [census lo, census hi, cost per item ...]
+            st.dev = torch.zeros(2 + n, dtype=torch.int32, device=self.device)       # [census word (lo, hi), cost per item ...]
             st.host = torch.zeros(2 + n, dtype=torch.int32).pin_memory()
+            st.np = st.host.numpy()          # numpy views of the pinned words, made once: a read costs no tensor indexing
+            st.census_np = st.np[:2].view("uint64")      # the census word
+            st.cost_np = st.np[2:2 + st.items]
+            st.census_ok = st.items * D < (1 << 20) and st.nwg < (1 << 13)     # (18-bit step counts in units of 4, 14-bit window / segment counts)
             st.shares_dev = torch.zeros(max(st.nwg, 1), 2, dtype=torch.int64, device=self.device)
             st.ring = [(torch.zeros(max(st.nwg, 1), 2, dtype=torch.int64).pin_memory(), torch.cuda.Event()) for _ in range(self.RING)]
             st.ring_used = [False] * self.RING
@@ -208,22 +215,25 @@ class BackwardPolicy:
         return st
 
     @staticmethod
-    def _census(host):
-        lo, hi = int(host[0]) & 0xFFFFFFFF, int(host[1]) & 0xFFFFFFFF     # little-endian halves of the 64-bit word
-        return hi, lo                                                      # gathered steps, all steps
+    def _census(word):
+        """(gathered steps, all steps, windows staged, segments) of a census word (include/movedepth_hip.h)"""
+        v = int(word[0])
+        return ((v >> 46) & 0x3FFFF) * 4, ((v >> 28) & 0x3FFFF) * 4, (v >> 14) & 0x3FFF, v & 0x3FFF
 
     def gathered_share(self, key=None):
         """Share of the last landed census' hypothesis steps that ran in gather mode (plain read of pinned memory: never waits)."""
         st = self._shapes.get(key) if key is not None else self._last
         if st is None:
             return 0.0
-        g, t = self._census(st.host)
+        if not st.census_ok:
+            return 0.0
+        g, t, _, _ = self._census(st.census_np)
         return g / t if t else 0.0
 
     def costs(self, key=None):
         """Per-item shader cycles of the last landed launch (numpy view of pinned memory)."""
         st = self._shapes.get(key) if key is not None else self._last
-        return None if st is None or st.items == 0 else st.host[2:2 + st.items].numpy()
+        return None if st is None or st.items == 0 else st.cost_np
 
     def partition(self, cost, nwg, D, quantum=8):
         """[lo, hi) per workgroup in step units (item * D + d): equal cost per workgroup, boundaries on multiples of `quantum` steps
@@ -249,7 +259,7 @@ class BackwardPolicy:
         if st.items == 0:
             return flags, base, None, 0, None
         shares, n = None, 0
-        cost = st.host[2:2 + st.items].numpy()
+        cost = st.cost_np
         want = self.force_balance
         if want is None:
             tot = float(cost.sum())
@@ -266,20 +276,42 @@ class BackwardPolicy:
                 self.balanced_launches += 1
         return flags, base, shares, n, base + 8
 
+    def windows_per_segment(self, key=None):
+        """Windows the last landed backward staged per segment: 1 when every tile's sweep fits its window (sane poses), more under parallax."""
+        st = self._shapes.get(key) if key is not None else self._last
+        if st is None:
+            return 0.0
+        _, _, wnd, seg = self._census(st.census_np)
+        return wnd / seg if seg else 0.0
+
+    def forward_flags(self, key, fp32):
+        """MD_CV_FINE_SLICES for the forward of this shape when the last landed backward of the same shape shows parallax (windows per
+        segment off 1 by more than `fine_above` - 1, or anything gathered): twice the slices even out what the tiles' unequal sweeps make uneven
+        (csrc/costvol.hip launch_cl_inst); fp32 only (the 2-byte forward loses more to the second staging than it gains)."""
+        if self.force_fine is not None:
+            return _lib.CV_FINE_SLICES if self.force_fine else 0
+        if not fp32 or key not in self._shapes:
+            return 0
+        wps = self.windows_per_segment(key)   # exactly 1 when every tile's sweep fits its window; sub-slices raise it, gathered ones lower it
+        on = wps > 0 and (abs(wps - 1.0) > self.fine_above - 1.0 or self.gathered_share(key) > 0.005)
+        self.fine_launches += int(on)
+        return _lib.CV_FINE_SLICES if on else 0
+
     def after_launch(self, key):
         st = self._shapes[key]
         st.host.copy_(st.dev, non_blocking=True)   # stream-ordered behind the launch; the host does not wait for it
 
     def last_census(self):
-        """(gathered steps, all steps) of the most recent launch, read from the DEVICE (synchronises: tests and tools only)."""
-        return self._census(self._last.dev[:2].cpu())
+        """(gathered steps, all steps, windows staged, segments) of the most recent launch (steps counted in units of 4 per workgroup), read from the DEVICE
+        (synchronises: tests and tools only)."""
+        return self._census(self._last.dev[:2].cpu().numpy().view("uint64"))
 
     def reset(self):
         """forget every shape's history (tests)"""
         torch.cuda.synchronize()
         self._shapes.clear()
         self._last = None
-        self.force_table = self.force_balance = None
+        self.force_table = self.force_balance = self.force_fine = None
 
     # round-6 name of the first half of this object (tests, tools)
     @property
@@ -335,8 +367,9 @@ class _CostVolume(torch.autograd.Function):
         K, invK, pose = _prep(K, "K"), _prep(invK, "invK"), _prep(pose, "pose")
         hyp, prior, ztrans = _prep(hyp, "depth_priors"), _prep(prior, "prior"), _prep(ztrans, "z_trans")
         store, (sb, sd, sg, sp), out = _vol_alloc(layout, B, D, G, h, w, ref.device, io)
+        fflags = backward_policy(ref.device).forward_flags((B, C, G, h, w, D, bool(fcl), layout == "ndhwc"), io == torch.float32)
         _timed_call("md_costvol_fwd" + sfx, _p(ref), _p(src), _p(K), _p(invK), _p(pose), _p(hyp), _p(prior), _p(ztrans),
-                    float(scale_fac), int(sched_type), B, C, G, h, w, D, int(fcl), _p(store), sb, sd, sg, sp, _stream())
+                    float(scale_fac), int(sched_type), B, C, G, h, w, D, int(fcl), _p(store), sb, sd, sg, sp, fflags, _stream())
         ctx.sfx, ctx.io, ctx.fcl = sfx, io, fcl
         ctx.save_for_backward(ref, src, K, invK, pose, hyp if hyp is not None else torch.empty(0),
                               prior if prior is not None else torch.empty(0),

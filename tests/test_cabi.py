@@ -44,7 +44,7 @@ def test_invalid_arguments_fail_loudly_without_a_gpu():
     from movedepth_amd import _lib
 
     lib = _lib.load()
-    rc = lib.md_costvol_fwd(None, None, None, None, None, None, None, None, 0.3, 0, 1, 32, 16, 8, 8, 4, 0, None, 0, 0, 0, 0, None)
+    rc = lib.md_costvol_fwd(None, None, None, None, None, None, None, None, 0.3, 0, 1, 32, 16, 8, 8, 4, 0, None, 0, 0, 0, 0, 0, None)
     assert rc == -1
     assert b"null" in lib.md_last_error()
     with pytest.raises(_lib.MovedepthHipError):
