@@ -1015,7 +1015,7 @@ int launch(const CvPtrs &q, CvDims dm, hipStream_t stream) {
     return launch_gen1<BWD>(q, dm, stream, BWD ? MD_CV_STR(MD_CV_NAME(md_costvol_bwd)) : MD_CV_STR(MD_CV_NAME(md_costvol_fwd)));
 }
 
-// First-generation kernels (planar volumes, other channel groupings; and the wild-pose samples of a channels-last backward)
+// First-generation kernels (planar volumes, other channel groupings)
 template <bool BWD>
 int launch_gen1(const CvPtrs &q, CvDims dm, hipStream_t stream, const char *tname) {
     const int N = dm.C / dm.G;

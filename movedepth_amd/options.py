@@ -121,6 +121,10 @@ class MonodepthOptions:
         p.add_argument("--force_sync_bn", type=int, default=0,
                        help="measurement: run the synchronised-BatchNorm path of --sync_bn_impl without --ddp (a group of one)")
         p.add_argument("--grad_bucket_mb", type=float, default=32.0, help="with --ddp: all-reduce bucket size")
+        p.add_argument("--direct_rccl", type=int, default=int(os.environ.get("MD_DIRECT_RCCL", "0")),
+                       help="with --ddp on the nccl backend: every collective of the step (BatchNorm statistics and gradient buckets) as "
+                            "ncclAllReduce on the compute stream through one communicator (rccl_direct.py) instead of torch's group and its "
+                            "stream; default: the MD_DIRECT_RCCL environment variable of the LAUNCHER, else 0")
         self.parser = p
 
     def parse(self, args=None):

@@ -1,4 +1,4 @@
-"""Small all-reduces issued straight to RCCL on the CALLING stream.  OPT-IN: MD_DIRECT_RCCL=1.
+"""Small all-reduces issued straight to RCCL on the CALLING stream.  OPT-IN: --direct_rccl 1 (default: MD_DIRECT_RCCL=1 of the launcher).
 
 Why.  A synchronised-BatchNorm step has 230 all-reduces of a few hundred bytes, each between two kernels that depend on it.
 torch.distributed runs a collective on the process group's own stream: an event recorded on the compute stream, a wait on the
@@ -92,8 +92,11 @@ def run_stages(stages, group=None, device=None, label="rccl_direct"):
     return state
 
 
+ENABLED = None   # set by the trainer from --direct_rccl; None: the launcher's MD_DIRECT_RCCL
+
+
 def enabled():
-    return os.environ.get("MD_DIRECT_RCCL", "0") == "1"
+    return bool(ENABLED) if ENABLED is not None else os.environ.get("MD_DIRECT_RCCL", "0") == "1"
 
 
 def make(group=None):

@@ -117,6 +117,7 @@ class Trainer:
         self.direct_all_reduce = None
         if opt.ddp and opt.sync_bn:
             from . import rccl_direct
+            rccl_direct.ENABLED = bool(getattr(opt, "direct_rccl", 0))
             self.direct_all_reduce = rccl_direct.make(None) if opt.sync_bn_impl == "hip" else None
             bn_group = self.direct_all_reduce or dist.group.WORLD
         self.bn_group = bn_group
