@@ -171,7 +171,7 @@ class BackwardPolicy:
         (max / mean above `imbalance`) and next to nothing is gathered: all workgroups of the backward are resident at once, so
         nothing else evens out what parallax makes uneven -- a driving-scene launch lasts as long as its slowest tile
         (csrc/costvol.hip launch_cl_inst; 107.9 -> 98.4 us at 1 m per frame, profiles/r06_costvol_spec.txt).  The measure is noisy --
-        equal tiles differ by 1.5-1.8x in cycles with where they ran -- so the bar is high (2.2; sane launches stay on the library's
+        equal tiles differ by 1.5-1.8x in cycles with where they ran -- so the bar is high (2.0; sane launches read 1.2-1.8 and stay on the library's
         own partition, d_ref stored without a fill), and launches with gathered sub-slices are left alone: their tail is the chip's
         atomic rate, which no partition changes (moderate poses: 122.9 -> 142.8 us balanced).
       * MD_CV_FINE_SLICES for the FORWARD of the same shape (fp32) when the last backward staged more than `fine_above` windows per
@@ -180,7 +180,7 @@ class BackwardPolicy:
 
     RING = 4   # pinned upload buffers per shape: one is rewritten only after its copy has completed (event), else the launch goes unbalanced
 
-    def __init__(self, device, threshold=0.45, imbalance=2.2, max_gathered_for_balance=0.05):
+    def __init__(self, device, threshold=0.45, imbalance=2.0, max_gathered_for_balance=0.05):
         self.device = device
         self.threshold, self.imbalance, self.max_gathered = float(threshold), float(imbalance), float(max_gathered_for_balance)
         self.force_table = self.force_balance = self.force_fine = None
