@@ -91,6 +91,101 @@ struct Moments {
     float mux, muy, ex2, ey2, exy;
 };
 
+// Two values per register pair.  v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 round each half exactly as the one-value
+// instructions do, so arithmetic written on pairs is bit-identical to the same arithmetic written value by value -- at half the
+// vector-ALU instructions, PROVIDED the pairs are born adjacent (the two halves of a 16-byte LDS record, two accumulators that
+// are always updated together).  photo.hip is compiled with -fno-slp-vectorize: the compiler's own pairing of this code spent
+// one v_mov per packed operation gathering operands (500 of the backward's 2600 vector instructions) and 20 more registers.
+#ifndef MD_PHOTO_FAST_DIV
+#define MD_PHOTO_FAST_DIV 1   // 0: every quotient of the fused kernels as a plain `/` (A/B builds)
+#endif
+using v2f = float __attribute__((ext_vector_type(2)));
+using v4f = float __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ v2f md_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ float md_fma(float a, float b, float c) { return fmaf(a, b, c); }
+__device__ __forceinline__ v2f div9(v2f x) {   // div_by per half
+#pragma clang fp contract(off)
+    const v2f q = x * (1.f / 9.f);
+    return md_fma(md_fma(-q, (v2f)9.f, x), (v2f)(1.f / 9.f), q);
+}
+
+// IEEE quotient n / d as the compiler's own expansion computes it -- v_rcp_f32, one Newton step on the reciprocal, q = n r, two
+// residual corrections (each an exact fma) -- WITHOUT that expansion's range scaling (two v_div_scale_f32, v_div_fmas_f32), which
+// is the identity unless d is subnormal or >= 2^126, |n| < 2^-103, or the exponents of n and d differ by 96 or more (ISA:
+// V_DIV_SCALE_F32): inside that range the bits are those of `n / d` (asserted against the per-operation kernels, which divide
+// with `/`, in tests/test_photo_fused.py).  What the caller gains: the steps pack (two quotients per instruction), a divisor
+// shared by several numerators is inverted once, and 11 instructions become 8.  md_div_fixup restores the IEEE results for zero /
+// infinite / NaN operands where a caller can meet them.
+__device__ __forceinline__ float md_rcp_newton(float d) {
+    const float r = __builtin_amdgcn_rcpf(d);
+    return fmaf(fmaf(-d, r, 1.f), r, r);
+}
+__device__ __forceinline__ v2f md_rcp_newton(v2f d) {
+    const v2f r = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+    return md_fma(md_fma(-d, r, (v2f)1.f), r, r);
+}
+template <class T>
+__device__ __forceinline__ T md_div_core(T n, T d, T r /* md_rcp_newton(d) */) {
+#pragma clang fp contract(off)
+    const T q0 = n * r;
+    const T q1 = md_fma(md_fma(-d, q0, n), r, q0);
+    return md_fma(md_fma(-d, q1, n), r, q1);
+}
+__device__ __forceinline__ float md_div_fixup(float q, float d, float n) { return __builtin_amdgcn_div_fixupf(q, d, n); }
+
+// md_project_r with the x and y rows of P = (K T)[:3] side by side: every operation of the two rows is the same instruction on a
+// register pair, and the two quotients by zz share its reciprocal.  Operation for operation md_project_r (bit-equal sample grid;
+// tests/test_photo_fused.py against md_warp_fwd and against the reference's fixtures).
+struct CamPk {
+    v2f Pxy[4];   // (P[0][j], P[1][j])
+    float Pz[4];  // P[2][j]
+};
+struct ProjPk {
+    v2f uv, g, i;   // (u, v) = cam.xy / zz; normalised grid coordinates; sample position in source pixels
+    float zz;
+};
+__device__ __forceinline__ ProjPk md_project_pk(const CamPk &m, float r0, float r1, float r2, float d, v2f wh1 /* (W-1, H-1) */,
+                                                v2f rwh /* RN(1 / wh1) */) {
+#pragma clang fp contract(off)
+    ProjPk p;
+    const float X = d * r0, Y = d * r1, Z = d * r2;
+    const v2f c01 = md_fma(m.Pxy[2], (v2f)Z, md_fma(m.Pxy[1], (v2f)Y, m.Pxy[0] * X)) + m.Pxy[3];
+    const float c2 = fmaf(m.Pz[2], Z, fmaf(m.Pz[1], Y, m.Pz[0] * X)) + m.Pz[3];
+    p.zz = c2 + 1e-7f;
+#if MD_PHOTO_FAST_DIV
+    // |zz| is 0 or >= 2^-47 (the spacing of floats at 1e-7) and |cam.xy| is far below 2^49 for any pose a frame can have: no
+    // scaling case; zz == 0 (and infinities, NaN) through v_div_fixup_f32 as in the compiler's expansion
+    const v2f q = md_div_core(c01, (v2f)p.zz, (v2f)md_rcp_newton(p.zz));
+    p.uv = (v2f){md_div_fixup(q.x, p.zz, c01.x), md_div_fixup(q.y, p.zz, c01.y)};
+#else
+    p.uv = c01 / p.zz;
+#endif
+    const v2f qn = p.uv * rwh;
+    p.g = (md_fma(md_fma(-qn, wh1, p.uv), rwh, qn) - 0.5f) * 2.f;   // div_by(uv, wh1, rwh)
+    p.i = ((p.g + 1.f) / 2.f) * wh1;
+    return p;
+}
+
+template <class T>
+struct MomentsT {
+    T mux, muy, ex2, ey2, exy;
+};
+
+// ssim_from on one value or on a pair: the same operations in the same order
+template <class T>
+__device__ __forceinline__ T ssim_from_t(const MomentsT<T> &m) {
+#pragma clang fp contract(off)
+    const T sx = m.ex2 - m.mux * m.mux, sy = m.ey2 - m.muy * m.muy, sxy = m.exy - m.mux * m.muy;
+    const T n = (2.f * m.mux * m.muy + kC1) * (2.f * sxy + kC2);
+    const T d = (m.mux * m.mux + m.muy * m.muy + kC1) * (sx + sy + kC2);
+#if MD_PHOTO_FAST_DIV
+    // d >= C1 (C2 - rounding noise) ~ 2^-24 and |n| / d < 2^30 for images of magnitude up to 2^20: no scaling case
+    return (1.f - md_div_core(n, d, md_rcp_newton(d))) / 2.f;
+#else
+    return (1.f - n / d) / 2.f;
+#endif
+}
+
 __device__ __forceinline__ float ssim_from(const Moments &m, float *n_out, float *d_out) {
     // as the reference's tensor expressions (layers.py:670-677): every product and difference rounded on its own
 #pragma clang fp contract(off)
@@ -119,5 +214,33 @@ __device__ __forceinline__ void ssim_coeffs(const Moments &m, float gs, float &A
         Cc = gs * (-0.5f * (2.f * A1) * rd);
     }
 }
+
+// ssim_coeffs on one value or on a pair (the backward's coefficient maps; a gradient: 1e-4 parity, not bit parity -- but the
+// clamp's pass band is decided on the forward's bits).  The reciprocal of d serves the forward quotient and the derivatives.
+template <class T>
+__device__ __forceinline__ void ssim_coeffs_t(const MomentsT<T> &m, float gs, T &A, T &Bc, T &Cc, T &raw) {
+    T n, d, sx, sy, sxy, rd;
+    {
+#pragma clang fp contract(off)
+        sx = m.ex2 - m.mux * m.mux; sy = m.ey2 - m.muy * m.muy; sxy = m.exy - m.mux * m.muy;
+        n = (2.f * m.mux * m.muy + kC1) * (2.f * sxy + kC2);
+        d = (m.mux * m.mux + m.muy * m.muy + kC1) * (sx + sy + kC2);
+        rd = md_rcp_newton(d);
+#if MD_PHOTO_FAST_DIV
+        raw = (1.f - md_div_core(n, d, rd)) / 2.f;
+#else
+        raw = (1.f - n / d) / 2.f;
+#endif
+    }
+    const T A1 = 2.f * m.mux * m.muy + kC1, A2 = 2.f * sxy + kC2;
+    const T B1 = m.mux * m.mux + m.muy * m.muy + kC1, B2 = sx + sy + kC2;
+    const T dn_dmux = 2.f * m.muy * A2 - 2.f * m.muy * A1;
+    const T dd_dmux = 2.f * m.mux * B2 - 2.f * m.mux * B1;
+    const T rd2 = rd * rd;
+    A = gs * (-0.5f * (dn_dmux * d - n * dd_dmux) * rd2);
+    Bc = gs * (0.5f * n * B1 * rd2);
+    Cc = gs * (-0.5f * (2.f * A1) * rd);
+}
+__device__ __forceinline__ bool md_in01(float raw) { return raw >= 0.f && raw <= 1.f; }  // clamp passes gradient only inside [0,1]
 
 }  // namespace mdp

@@ -41,6 +41,12 @@ constexpr int BT_W = 32, BT_H = 8;                                              
 #ifndef MD_PHOTO_BWD_WAVES
 #define MD_PHOTO_BWD_WAVES 4     // waves per SIMD the backward is compiled for (up to two source frames): 128 registers, 9 spilled at F = 2; 3: 135, none (A/B: 201 -> 177 us)
 #endif
+#ifndef MD_PHOTO_CAM_SGPR
+#define MD_PHOTO_CAM_SGPR 1   // camera matrices in scalar registers (A/B)
+#endif
+#ifndef MD_PHOTO_BWD_EARLY
+#define MD_PHOTO_BWD_EARLY 3   // bit 0: frame 0's tap loads before the coefficient phase; bit 1: frame f+1's before frame f's reductions (A/B)
+#endif
 #ifndef MD_PHOTO_FWD_WAVES
 #define MD_PHOTO_FWD_WAVES 3     // waves per SIMD the forward is compiled for (up to two source frames); A/B: tools/ab_build.sh
 #endif
@@ -52,31 +58,38 @@ constexpr int B1_W = BT_W + 2, B1_H = BT_H + 2, B1_N = B1_W * B1_H;             
 
 __device__ __forceinline__ float f4c(const float4 &v, int c) { return c == 0 ? v.x : (c == 1 ? v.y : v.z); }
 
-struct Sample3 {
-    float v[3];
-};
+// The four records of a bilinear footprint, from clamped addresses: one 32-bit byte offset from the image's (wave-uniform) base
+// and three additions -- as four 64-bit element addresses the loads cost 15 vector instructions per footprint.
+__device__ __forceinline__ void load_taps(const v4f *__restrict__ img, int W, const Tap &t, bool vx1, bool vy1, v4f &v00, v4f &v01, v4f &v10,
+                                          v4f &v11) {
+    const char *base = reinterpret_cast<const char *>(img);
+    const unsigned o00 = (unsigned)(t.y0 * W + t.x0) * 16u, dx = vx1 ? 16u : 0u, dy = vy1 ? (unsigned)W * 16u : 0u;
+    v00 = *reinterpret_cast<const v4f *>(base + o00);
+    v01 = *reinterpret_cast<const v4f *>(base + (o00 + dx));
+    v10 = *reinterpret_cast<const v4f *>(base + (o00 + dy));
+    v11 = *reinterpret_cast<const v4f *>(base + (o00 + dy + dx));
+}
 
 // grid_sample(border, align_corners=True) of a packed image at the clipped position (the forward of warp.hip).
-// The four loads are unconditional, from clamped addresses, and selected to zero afterwards: a load under a (divergent)
-// branch sits in its own basic block behind an s_waitcnt, which made the taps SERIAL memory round trips (the 4-scale forward
-// spent 72 % of its wave cycles parked; so does warp_fwd_kernel, 13 us for 0.7 M pixels).
-__device__ __forceinline__ Sample3 sample_border(const float4 *__restrict__ img, int W, int H, const Clip &c) {
+// The four loads are unconditional, from clamped addresses: a load under a (divergent) branch sits in its own basic block behind
+// an s_waitcnt, which made the taps SERIAL memory round trips (the 4-scale forward spent 72 % of its wave cycles parked; so does
+// warp_fwd_kernel, 13 us for 0.7 M pixels).  A tap beyond the last column / row needs no select either: border clipping puts
+// such a position ON the integer W-1 / H-1, so its weight wx1 / wy1 is exactly 0, and the value read from the clamped address
+// instead is a finite pixel: the product is the exact zero md_warp_fwd adds there.  The interpolation is grid_sample's in the
+// reference's order (as warp_fwd_kernel and the oracle's tap_sample: bit-equal results), on the (R, G) and (B, pad) halves of
+// the 16-byte records: 8 packed instructions instead of 12 + 9 selects.  The pad lane of the result is not defined.
+__device__ __forceinline__ v4f sample_border(const v4f *__restrict__ img, int W, int H, const Clip &c) {
     const Tap t = md_make_tap(c.ix, c.iy, W, H);
     const bool vx1 = t.x0 + 1 < W, vy1 = t.y0 + 1 < H;  // x0, y0 are in range after clipping
-    const int x1 = vx1 ? t.x0 + 1 : t.x0, y1 = vy1 ? t.y0 + 1 : t.y0;
     const float wx0 = 1.f - t.wx1, wy0 = 1.f - t.wy1;
-    const float4 v00 = img[t.y0 * W + t.x0], v01 = img[t.y0 * W + x1], v10 = img[y1 * W + t.x0], v11 = img[y1 * W + x1];
-    Sample3 o;
-#pragma unroll
-    for (int ch = 0; ch < 3; ++ch) {
-        // grid_sample's interpolation in the reference's order (as warp_fwd_kernel and the oracle's tap_sample: bit-equal results);
-        // a tap that is out of range adds an exact zero
+    v4f v00, v01, v10, v11;
+    load_taps(img, W, t, vx1, vy1, v00, v01, v10, v11);
+    v4f o;
+    {
 #pragma clang fp contract(off)
-        float a = f4c(v00, ch) * (wy0 * wx0);
-        a = fmaf(vx1 ? f4c(v01, ch) : 0.f, wy0 * t.wx1, a);
-        a = fmaf(vy1 ? f4c(v10, ch) : 0.f, t.wy1 * wx0, a);
-        a = fmaf((vx1 && vy1) ? f4c(v11, ch) : 0.f, t.wy1 * t.wx1, a);
-        o.v[ch] = a;
+        const float w00 = wy0 * wx0, w01 = wy0 * t.wx1, w10 = t.wy1 * wx0, w11 = t.wy1 * t.wx1;
+        o.xy = md_fma(v11.xy, (v2f)w11, md_fma(v10.xy, (v2f)w10, md_fma(v01.xy, (v2f)w01, v00.xy * w00)));
+        o.zw = md_fma(v11.zw, (v2f)w11, md_fma(v10.zw, (v2f)w10, md_fma(v01.zw, (v2f)w01, v00.zw * w00)));
     }
     return o;
 }
@@ -97,7 +110,7 @@ __host__ inline unsigned photo_grid(int nitems, int S) { return 8u * (unsigned)(
 
 // P = (K T)[:3] of every frame and inv_K[:3,:3], computed once per workgroup (12 F + 9 threads), read back by everyone
 template <int F>
-__device__ __forceinline__ void load_cams(const md_photo_desc &a, int b, float *camS /*[F*12+9]*/, CamMats (&cam)[F]) {
+__device__ __forceinline__ void load_cams_lds(const md_photo_desc &a, int b, float *camS /*[F*12+9]*/) {
     const int tid = threadIdx.x;
     if (tid < 12 * F) {
         const int f = tid / 12, i = (tid % 12) / 4, j = tid % 4;
@@ -114,6 +127,10 @@ __device__ __forceinline__ void load_cams(const md_photo_desc &a, int b, float *
         camS[tid] = a.invK[b * 16 + (k / 3) * 4 + k % 3];
     }
     __syncthreads();
+}
+template <int F>
+__device__ __forceinline__ void load_cams(const md_photo_desc &a, int b, float *camS, CamMats (&cam)[F]) {
+    load_cams_lds<F>(a, b, camS);
 #pragma unroll
     for (int f = 0; f < F; ++f) {
 #pragma unroll
@@ -121,6 +138,23 @@ __device__ __forceinline__ void load_cams(const md_photo_desc &a, int b, float *
 #pragma unroll
         for (int k = 0; k < 9; ++k) cam[f].iK[k] = camS[F * 12 + k];
     }
+}
+// the same with the x and y rows of P as register pairs (md_project_pk)
+template <int F>
+__device__ __forceinline__ void load_cams_pk(const md_photo_desc &a, int b, float *camS, CamPk (&cam)[F], float (&iK)[9]) {
+    load_cams_lds<F>(a, b, camS);
+    // the matrices are the same in every lane: v_readfirstlane_b32 moves them to scalar registers, which the vector instructions
+    // read directly (12 F + 9 vector registers less: what lets the backward keep a frame's taps in flight, see issue_taps)
+    auto uni = [](float v) { return MD_PHOTO_CAM_SGPR ? __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))) : v; };
+#pragma unroll
+    for (int f = 0; f < F; ++f)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            cam[f].Pxy[j] = (v2f){uni(camS[f * 12 + j]), uni(camS[f * 12 + 4 + j])};
+            cam[f].Pz[j] = uni(camS[f * 12 + 8 + j]);
+        }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) iK[k] = uni(camS[F * 12 + k]);
 }
 
 // ------------------------------------------------------------------------------------------------ forward
@@ -138,12 +172,13 @@ __global__ __launch_bounds__(256, (F <= 2 ? MD_PHOTO_FWD_WAVES : 2)) void photo_
     if (!photo_item(a.B * tiles, IDENT ? 1 : a.S, item, s)) return;
     const int b = item / tiles, tile = item % tiles;
     const int x0 = (tile % tiles_x) * FT_W, y0 = (tile / tiles_x) * FT_H;
-    CamMats cam[F];
-    if (!IDENT) load_cams<F>(a, b, camS, cam);
+    CamPk cam[F];
+    float iK[9];
+    if (!IDENT) load_cams_pk<F>(a, b, camS, cam, iK);
     const size_t HW = (size_t)H * W;
     const float4 *tgt = reinterpret_cast<const float4 *>(a.target) + (size_t)b * HW;
     const float min_disp = 1.f / a.max_depth, max_disp = 1.f / a.min_depth;
-    const float wm1 = (float)(W - 1), hm1 = (float)(H - 1), rw = 1.f / wm1, rh = 1.f / hm1;
+    const v2f wh1 = {(float)(W - 1), (float)(H - 1)}, rwh = {1.f / wh1.x, 1.f / wh1.y};
 
     // ---- phase 1: every halo position -> target + F predictions in LDS.  Unrolled: the loads of a thread's (up to) three
     // positions are independent and should all be in flight together -- the kernel is bound by memory latency, not bandwidth
@@ -161,23 +196,36 @@ __global__ __launch_bounds__(256, (F <= 2 ? MD_PHOTO_FWD_WAVES : 2)) void photo_
             // the pixel this thread also writes the per-pixel outputs of (the interior of the tile, inside the image)
             const bool own = cy >= 1 && cy <= FT_H && cx >= 1 && cx <= FT_W && gy < H && gx < W;
             float depth;
-            if (a.is_disp) depth = 1.f / disp_up_sd(a.dz[s] + (size_t)b * a.dh[s] * a.dw[s], a.dh[s], a.dw[s], H, W, py, px, min_disp, max_disp);
-            else depth = a.dz[s][(size_t)b * HW + p];
+            if (a.is_disp) {
+                const float sd = disp_up_sd(a.dz[s] + (size_t)b * a.dh[s] * a.dw[s], a.dh[s], a.dw[s], H, W, py, px, min_disp, max_disp);
+#if MD_PHOTO_FAST_DIV
+                depth = md_div_fixup(md_div_core(1.f, sd, md_rcp_newton(sd)), sd, 1.f);   // sd in [1 / max_depth, 1 / min_depth]
+#else
+                depth = 1.f / sd;
+#endif
+            } else {
+                depth = a.dz[s][(size_t)b * HW + p];
+            }
             if (own && a.depth_out[s]) a.depth_out[s][(size_t)b * HW + p] = depth;
-            float r0, r1, r2;
-            md_ray(cam[0], (float)px, (float)py, r0, r1, r2);   // inv_K is the same for every frame
+            float r0, r1, r2;   // inv_K is the same for every frame (md_ray's operations)
+            {
+#pragma clang fp contract(off)
+                r0 = fmaf(iK[1], (float)py, iK[0] * (float)px) + iK[2];
+                r1 = fmaf(iK[4], (float)py, iK[3] * (float)px) + iK[5];
+                r2 = fmaf(iK[7], (float)py, iK[6] * (float)px) + iK[8];
+            }
 #pragma unroll
             for (int f = 0; f < F; ++f) {
-                const Proj pr = md_project_r(cam[f], r0, r1, r2, depth, wm1, hm1, rw, rh);
-                const Clip c = clip_border(pr.ix, pr.iy, W, H);
-                const Sample3 o = sample_border(reinterpret_cast<const float4 *>(a.src[f]) + (size_t)b * HW, W, H, c);
-                const float4 o4 = make_float4(o.v[0], o.v[1], o.v[2], 0.f);
-                wp[f * FP_N + i] = o4;
+                const ProjPk pr = md_project_pk(cam[f], r0, r1, r2, depth, wh1, rwh);
+                const Clip c = clip_border(pr.i.x, pr.i.y, W, H);
+                v4f o4 = sample_border(reinterpret_cast<const v4f *>(a.src[f]) + (size_t)b * HW, W, H, c);
+                o4.w = 0.f;
+                reinterpret_cast<v4f *>(wp)[f * FP_N + i] = o4;
                 if (own) {
-                    if (a.warped[s][f]) (reinterpret_cast<float4 *>(a.warped[s][f]) + (size_t)b * HW)[p] = o4;
-                    if (a.pix[s][f]) *reinterpret_cast<float2 *>(a.pix[s][f] + ((size_t)b * HW + p) * 2) = make_float2(pr.gx, pr.gy);
+                    if (a.warped[s][f]) (reinterpret_cast<v4f *>(a.warped[s][f]) + (size_t)b * HW)[p] = o4;
+                    if (a.pix[s][f]) *reinterpret_cast<v2f *>(a.pix[s][f] + ((size_t)b * HW + p) * 2) = pr.g;
                     if (s == 0 && a.oob[f])
-                        a.oob[f][(size_t)b * HW + p] = (pr.gx < -1.f || pr.gx > 1.f || pr.gy < -1.f || pr.gy > 1.f) ? 1 : 0;
+                        a.oob[f][(size_t)b * HW + p] = (pr.g.x < -1.f || pr.g.x > 1.f || pr.g.y < -1.f || pr.g.y > 1.f) ? 1 : 0;
                 }
             }
         }
@@ -194,65 +242,79 @@ __global__ __launch_bounds__(256, (F <= 2 ? MD_PHOTO_FWD_WAVES : 2)) void photo_
         // taps row-major in float, over tensors of already-rounded products x*x, x*y (layers.py:663-672) -- because
         // sigma = E[x^2] - mu^2 cancels to 1e-3 of its terms on smooth images and any other association moves the loss by ~1e-4.
 #pragma clang fp contract(off)
-        // pixel k = 0 uses LDS rows 2rp .. 2rp+2, pixel k = 1 rows 2rp+1 .. 2rp+3; both walk rows and columns in ascending order
-        float muy[2][3], ey2[2][3], yc[2][3];
+        // pixel k = 0 uses LDS rows 2rp .. 2rp+2, pixel k = 1 rows 2rp+1 .. 2rp+3; both walk rows and columns in ascending order.
+        // Every sum lives in three register pairs: (R, G) of pixel 0, (R, G) of pixel 1 -- the low half of the 16-byte LDS record --
+        // and (B of pixel 0, B of pixel 1): the two middle rows feed both pixels, so their B tap is added to both halves of that
+        // pair in one instruction.  30 packed / single instructions per sum of 54 additions (md_photo.hpp: same bits).
+        const v4f *tgv = reinterpret_cast<const v4f *>(tg);
+        v2f muy[3], ey2[3];   // [0], [1]: (R, G) of pixel k; [2]: B of both
+        v4f yc[2];
 #pragma unroll
-        for (int k = 0; k < 2; ++k)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) muy[k][c] = ey2[k][c] = 0.f;
+        for (int g = 0; g < 3; ++g) muy[g] = ey2[g] = (v2f)0.f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int o = (2 * rp + r) * FP_W + tx;
-            const float4 t[3] = {tg[o], tg[o + 1], tg[o + 2]};
 #pragma unroll
-            for (int j = 0; j < 3; ++j)
+            for (int j = 0; j < 3; ++j) {
+                const v4f t = tgv[o + j];
+                const v2f t0 = t.xy, q0 = t0 * t0;
+                const float qz = t.z * t.z;
+                if (r <= 2) { muy[0] += t0; ey2[0] += q0; }
+                if (r >= 1) { muy[1] += t0; ey2[1] += q0; }
+                if (r == 0) { muy[2].x += t.z; ey2[2].x += qz; }
+                else if (r == 3) { muy[2].y += t.z; ey2[2].y += qz; }
+                else { muy[2] += (v2f)t.z; ey2[2] += (v2f)qz; }
+                if (j == 1 && r == 1) yc[0] = t;
+                if (j == 1 && r == 2) yc[1] = t;
+            }
+        }
+        v2f my[3], ey[3];   // window means of the target
+        if (use_ssim) {
 #pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const float v = f4c(t[j], c), vv = v * v;
-                    if (r <= 2) { muy[0][c] += v; ey2[0][c] += vv; }
-                    if (r >= 1) { muy[1][c] += v; ey2[1][c] += vv; }
-                    if (j == 1 && r == 1) yc[0][c] = v;
-                    if (j == 1 && r == 2) yc[1][c] = v;
-                }
+            for (int g = 0; g < 3; ++g) { my[g] = div9(muy[g]); ey[g] = div9(ey2[g]); }
         }
 #pragma unroll
         for (int f = 0; f < F; ++f) {
-            const float4 *wf = wp + f * FP_N;
-            float mux[2][3], ex2[2][3], exy[2][3], xc[2][3];
+            const v4f *wf = reinterpret_cast<const v4f *>(wp + f * FP_N);
+            v2f mux[3], ex2[3], exy[3];
+            v4f xc[2];
 #pragma unroll
-            for (int k = 0; k < 2; ++k)
-#pragma unroll
-                for (int c = 0; c < 3; ++c) mux[k][c] = ex2[k][c] = exy[k][c] = 0.f;
+            for (int g = 0; g < 3; ++g) mux[g] = ex2[g] = exy[g] = (v2f)0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int o = (2 * rp + r) * FP_W + tx;
-                const float4 xv[3] = {wf[o], wf[o + 1], wf[o + 2]};
-                const float4 t[3] = {tg[o], tg[o + 1], tg[o + 2]};
 #pragma unroll
-                for (int j = 0; j < 3; ++j)
+                for (int j = 0; j < 3; ++j) {
+                    const v4f x = wf[o + j], t = tgv[o + j];
+                    const v2f x0 = x.xy, q0 = x0 * x0, p0 = x0 * t.xy;
+                    const float qz = x.z * x.z, pz = x.z * t.z;
+                    if (r <= 2) { mux[0] += x0; ex2[0] += q0; exy[0] += p0; }
+                    if (r >= 1) { mux[1] += x0; ex2[1] += q0; exy[1] += p0; }
+                    if (r == 0) { mux[2].x += x.z; ex2[2].x += qz; exy[2].x += pz; }
+                    else if (r == 3) { mux[2].y += x.z; ex2[2].y += qz; exy[2].y += pz; }
+                    else { mux[2] += (v2f)x.z; ex2[2] += (v2f)qz; exy[2] += (v2f)pz; }
+                    if (j == 1 && r == 1) xc[0] = x;
+                    if (j == 1 && r == 2) xc[1] = x;
+                }
+            }
+            // SSIM of three pairs: (R, G) of pixel 0, (R, G) of pixel 1, B of both
+            v2f sv[3] = {(v2f)0.f, (v2f)0.f, (v2f)0.f};
+            if (use_ssim) {
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        const float v = f4c(xv[j], c), vv = v * v, vy = v * f4c(t[j], c);
-                        if (r <= 2) { mux[0][c] += v; ex2[0][c] += vv; exy[0][c] += vy; }
-                        if (r >= 1) { mux[1][c] += v; ex2[1][c] += vv; exy[1][c] += vy; }
-                        if (j == 1 && r == 1) xc[0][c] = v;
-                        if (j == 1 && r == 2) xc[1][c] = v;
-                    }
+                for (int g = 0; g < 3; ++g) {
+                    MomentsT<v2f> m;
+                    m.mux = div9(mux[g]); m.ex2 = div9(ex2[g]); m.exy = div9(exy[g]);
+                    m.muy = my[g]; m.ey2 = ey[g];
+                    const v2f raw = ssim_from_t<v2f>(m);
+                    sv[g] = (v2f){fminf(fmaxf(raw.x, 0.f), 1.f), fminf(fmaxf(raw.y, 0.f), 1.f)};  // torch.clamp(., 0, 1)
+                }
             }
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
+                // channel sums in the reference's order: ((R + G) + B), from zero
                 float l1 = 0.f, ss = 0.f;
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    l1 += fabsf(yc[k][c] - xc[k][c]);
-                    if (use_ssim) {
-                        Moments m;
-                        m.mux = div9(mux[k][c]); m.ex2 = div9(ex2[k][c]); m.exy = div9(exy[k][c]);
-                        m.muy = div9(muy[k][c]); m.ey2 = div9(ey2[k][c]);
-                        const float sv = ssim_from(m, nullptr, nullptr);
-                        ss += fminf(fmaxf(sv, 0.f), 1.f);  // torch.clamp(., 0, 1)
-                    }
-                }
+                l1 += fabsf(yc[k].x - xc[k].x); l1 += fabsf(yc[k].y - xc[k].y); l1 += fabsf(yc[k].z - xc[k].z);
+                ss += sv[k].x; ss += sv[k].y; ss += (k == 0 ? sv[2].x : sv[2].y);
                 // mean over the three channels: an IEEE quotient by the constant 3 (div_by: 3 instructions, same bits)
                 l1 = div_by(l1, 3.f, 1.f / 3.f);
                 ss = div_by(ss, 3.f, 1.f / 3.f);
@@ -331,7 +393,7 @@ __global__ __launch_bounds__(256, (F <= 2 ? MD_PHOTO_BWD_WAVES : 2)) void photo_
     float4 *cf = lds + (1 + F) * B2_N;        // cf[k * B1_N + i], k = 0..2: coefficient maps A, B, C of the current frame
     __shared__ float redf[16 * 12];
     __shared__ float camS[MAXF * 12 + 9];
-    __shared__ signed char csel[B1_N];        // frame whose coefficients a halo-1 position holds (-1: none)
+    __shared__ int anyon[MAXF];               // does any halo-1 position of this tile hold coefficients of frame f?
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int H = a.H, W = a.W;
     const int tiles_x = (W + BT_W - 1) / BT_W, nblk = tiles_x * ((H + BT_H - 1) / BT_H);
@@ -341,7 +403,7 @@ __global__ __launch_bounds__(256, (F <= 2 ? MD_PHOTO_BWD_WAVES : 2)) void photo_
     const int x0 = (blk % tiles_x) * BT_W, y0 = (blk / tiles_x) * BT_H;
     const size_t HW = (size_t)H * W;
     const float min_disp = 1.f / a.max_depth, max_disp = 1.f / a.min_depth;
-    const float wm1 = (float)(W - 1), hm1 = (float)(H - 1), rw = 1.f / wm1, rh = 1.f / hm1;
+    const v2f wh1 = {(float)(W - 1), (float)(H - 1)}, rwh = {1.f / wh1.x, 1.f / wh1.y};
     const bool use_ssim = !a.no_ssim && a.ssim_w != 0.f;
     const float wl1 = a.no_ssim ? 1.f : (1.f - a.ssim_w);
     // d loss_s / d (min * mask)[p] = gloss_s / (sum(mask) + 1e-7)
@@ -360,8 +422,7 @@ __global__ __launch_bounds__(256, (F <= 2 ? MD_PHOTO_BWD_WAVES : 2)) void photo_
     // the Infinity Cache); as first written it chained nine dependent round trips per workgroup (camera matrices -> two staging
     // iterations -> per frame: selection bytes, then the twelve taps) and ran 316 us inside the training step.
     constexpr int NST = (B2_N + 255) / 256, NCF = (B1_N + 255) / 256;
-    using v4f = float __attribute__((ext_vector_type(4)));   // a first-class vector: an array of HIP's float4 structs stayed in scratch
-    v4f st[NST][1 + F];
+    v4f st[NST][1 + F];   // a first-class vector: an array of HIP's float4 structs stayed in scratch
     {
         const v4f *tgt = reinterpret_cast<const v4f *>(a.target) + (size_t)b * HW;
 #pragma unroll
@@ -395,13 +456,18 @@ __global__ __launch_bounds__(256, (F <= 2 ? MD_PHOTO_BWD_WAVES : 2)) void photo_
         const int cqy = qvalid ? qy : 0, cqx = qvalid ? qx : 0;
         if (a.is_disp) {
             sd = disp_up_sd(a.dz[s] + (size_t)b * a.dh[s] * a.dw[s], a.dh[s], a.dw[s], H, W, cqy, cqx, min_disp, max_disp);
+#if MD_PHOTO_FAST_DIV
+            depth = md_div_fixup(md_div_core(1.f, sd, md_rcp_newton(sd)), sd, 1.f);   // the forward's bits: the same taps
+#else
             depth = 1.f / sd;
+#endif
         } else {
             depth = a.dz[s][(size_t)b * HW + (size_t)cqy * W + cqx];
         }
     }
-    CamMats cam[F];
-    load_cams<F>(a, b, camS, cam);   // (barrier inside)
+    CamPk cam[F];
+    float iK[9];
+    load_cams_pk<F>(a, b, camS, cam, iK);   // (barrier inside)
 #pragma unroll
     for (int k = 0; k < NST; ++k) {
         const int i = tid + 256 * k;
@@ -424,50 +490,86 @@ __global__ __launch_bounds__(256, (F <= 2 ? MD_PHOTO_BWD_WAVES : 2)) void photo_
             const int i = tid + 256 * k;
             if (i >= B1_N) break;
             const int cy = i / B1_W, cx = i % B1_W;
-            float4 A = make_float4(0.f, 0.f, 0.f, 0.f), Bc = A, Cc = A;
+            float4 A = make_float4(0.f, 0.f, 0.f, -1.f), Bc = make_float4(0.f, 0.f, 0.f, 0.f), Cc = Bc;
             const int fs = selc[k] & 0x7f;
             const bool on = (selc[k] & 0x80) && fs < F && (only_f < 0 || fs == only_f);
             if (on) {
-                const float4 *wf = wp + fs * B2_N;
-                const float gs = gscale * mskc[k] * a.ssim_w / 3.f;
-                float cA[3], cB[3], cC[3];
+                const v4f *wf = reinterpret_cast<const v4f *>(wp + fs * B2_N), *tgv = reinterpret_cast<const v4f *>(tg);
+                const float gs = gscale * mskc[k] * a.ssim_w * (1.f / 3.f);
+                // each tap's 16-byte record is read from LDS once for its three channels (read per channel, the kernel issued 400
+                // DS instructions per wave and was LDS-bound: SQ_LDS_IDX_ACTIVE 60 % of its duration); (R, G) as a register pair,
+                // B on its own (md_photo.hpp); sums in the reference's order, no contraction (see the forward)
+                MomentsT<v2f> m2 = {(v2f)0.f, (v2f)0.f, (v2f)0.f, (v2f)0.f, (v2f)0.f};
+                MomentsT<float> mz = {0.f, 0.f, 0.f, 0.f, 0.f};
                 {
-                    // each tap's float4 is read from LDS once for its three channels (read per channel, the kernel issued 400
-                    // DS instructions per wave and was LDS-bound: SQ_LDS_IDX_ACTIVE 60 % of its duration); sums in the
-                    // reference's order, no contraction (see the forward)
 #pragma clang fp contract(off)
-                    Moments m[3];
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) m[c] = Moments{0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
                         for (int dx = 0; dx < 3; ++dx) {
-                            const float4 x4 = wf[(cy + dy) * B2_W + cx + dx], y4 = tg[(cy + dy) * B2_W + cx + dx];
-#pragma unroll
-                            for (int c = 0; c < 3; ++c) {
-                                const float xv = f4c(x4, c), yv = f4c(y4, c);
-                                m[c].mux += xv; m[c].muy += yv; m[c].ex2 += xv * xv; m[c].ey2 += yv * yv; m[c].exy += xv * yv;
-                            }
+                            const v4f x4 = wf[(cy + dy) * B2_W + cx + dx], y4 = tgv[(cy + dy) * B2_W + cx + dx];
+                            const v2f x = x4.xy, y = y4.xy;
+                            m2.mux += x; m2.muy += y; m2.ex2 += x * x; m2.ey2 += y * y; m2.exy += x * y;
+                            mz.mux += x4.z; mz.muy += y4.z; mz.ex2 += x4.z * x4.z; mz.ey2 += y4.z * y4.z; mz.exy += x4.z * y4.z;
+                            // one window row of LDS records in flight at a time: all 18 (72 registers) beside frame 0's taps spilled
+                            if ((MD_PHOTO_BWD_EARLY & 1) && dx == 2) __builtin_amdgcn_sched_barrier(0);
                         }
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        m[c].mux = div9(m[c].mux); m[c].muy = div9(m[c].muy); m[c].ex2 = div9(m[c].ex2);
-                        m[c].ey2 = div9(m[c].ey2); m[c].exy = div9(m[c].exy);
-                        ssim_coeffs(m[c], gs, cA[c], cB[c], cC[c]);
-                    }
+                    m2.mux = div9(m2.mux); m2.muy = div9(m2.muy); m2.ex2 = div9(m2.ex2); m2.ey2 = div9(m2.ey2); m2.exy = div9(m2.exy);
+                    mz.mux = div9(mz.mux); mz.muy = div9(mz.muy); mz.ex2 = div9(mz.ex2); mz.ey2 = div9(mz.ey2); mz.exy = div9(mz.exy);
                 }
-                A = make_float4(cA[0], cA[1], cA[2], 0.f);
-                Bc = make_float4(cB[0], cB[1], cB[2], 0.f);
-                Cc = make_float4(cC[0], cC[1], cC[2], 0.f);
+                v2f A2, B2, C2, raw2;
+                float Az, Bz, Cz, rawz;
+                ssim_coeffs_t<v2f>(m2, gs, A2, B2, C2, raw2);
+                ssim_coeffs_t<float>(mz, gs, Az, Bz, Cz, rawz);
+                const bool k0 = md_in01(raw2.x), k1 = md_in01(raw2.y), k2 = md_in01(rawz);
+                A = make_float4(k0 ? A2.x : 0.f, k1 ? A2.y : 0.f, k2 ? Az : 0.f, (float)fs);   // pad lane: the frame these belong to
+                Bc = make_float4(k0 ? B2.x : 0.f, k1 ? B2.y : 0.f, k2 ? Bz : 0.f, 0.f);
+                Cc = make_float4(k0 ? C2.x : 0.f, k1 ? C2.y : 0.f, k2 ? Cz : 0.f, 0.f);
             }
             cf[i] = A; cf[B1_N + i] = Bc; cf[2 * B1_N + i] = Cc;
-            csel[i] = on ? (signed char)fs : (signed char)-1;
+            if (on) anyon[fs] = 1;
         }
     };
-    float r0, r1, r2;
-    md_ray(cam[0], (float)qx, (float)qy, r0, r1, r2);
+    float r0, r1, r2;   // md_ray's operations
+    {
+#pragma clang fp contract(off)
+        r0 = fmaf(iK[1], (float)qy, iK[0] * (float)qx) + iK[2];
+        r1 = fmaf(iK[4], (float)qy, iK[3] * (float)qx) + iK[5];
+        r2 = fmaf(iK[7], (float)qy, iK[6] * (float)qx) + iK[8];
+    }
     float d_depth = 0.f;
+    // ---- a frame's four bilinear taps and what the warp's backward needs of the projection.  The loads are unconditional (see
+    // sample_border), for every pixel whether or not a gradient will reach it, and REQUESTED EARLY: frame 0's before the coefficient
+    // phase, frame f+1's before frame f's reductions and barrier -- a request issued at the top of its own frame's iteration was
+    // waited for with nothing left to overlap (the kernel spent 84 of its 203 us per step on those two round trips).
+    struct Taps {
+        v4f t0, t1, t2, t3;   // north-west, north-east, south-west, south-east
+        float pzz, wx1, wy1;
+        v2f puv, pg;
+    };
+    auto issue_taps = [&](int f) {
+        Taps o;
+        const ProjPk pr = md_project_pk(cam[f], r0, r1, r2, depth, wh1, rwh);
+        const Clip c = clip_border(pr.i.x, pr.i.y, W, H);
+        const Tap t = md_make_tap(c.ix, c.iy, W, H);
+        const bool vx1 = t.x0 + 1 < W, vy1 = t.y0 + 1 < H;
+        o.pzz = pr.zz; o.puv = pr.uv; o.pg = (v2f){c.gmx, c.gmy}; o.wx1 = t.wx1; o.wy1 = t.wy1;
+        load_taps(reinterpret_cast<const v4f *>(a.src[f]) + (size_t)b * HW, W, t, vx1, vy1, o.t0, o.t1, o.t2, o.t3);
+        __builtin_amdgcn_sched_barrier(0);   // keep the loads up here: the scheduler otherwise sinks them to their first use
+        return o;
+    };
+    Taps cur;
+    if (MD_PHOTO_BWD_EARLY & 1) cur = issue_taps(0);
+    // weights of the 3 x 3 coefficient gather, the same for every frame.  ReflectionPad2d adjoint: row 1 is also pad row -1 (seen by
+    // window row 0), row H-2 also pad row H; a neighbour outside the image contributes nothing.
+    float gwy[3], gwx[3];
+#pragma unroll
+    for (int d = -1; d <= 1; ++d) {
+        const int py = qy + d, px = qx + d;
+        gwy[d + 1] = (py < 0 || py >= H) ? 0.f : 1.f + ((qy == 1 && py == 0) ? 1.f : 0.f) + ((qy == H - 2 && py == H - 1) ? 1.f : 0.f);
+        gwx[d + 1] = (px < 0 || px >= W) ? 0.f : 1.f + ((qx == 1 && px == 0) ? 1.f : 0.f) + ((qx == W - 2 && px == W - 1) ? 1.f : 0.f);
+    }
+    if (tid < F) anyon[tid] = 0;
     __syncthreads();
     if (use_ssim && MD_PHOTO_BWD_ONEPASS) {
         coeff_phase(-1);
@@ -477,23 +579,9 @@ __global__ __launch_bounds__(256, (F <= 2 ? MD_PHOTO_BWD_WAVES : 2)) void photo_
 #pragma unroll
     for (int f = 0; f < F; ++f) {
         const float4 *wf = wp + f * B2_N;
-        // ---- the frame's four bilinear taps: requested now, for every pixel whether or not a gradient will reach it, and used
-        // after the coefficient phase below -- their latency hides behind that phase's LDS work (deciding first which pixels
-        // need them would put the loads behind it again; keeping both frames' taps live cost a wave per SIMD in registers)
-        float4 tv0, tv1, tv2, tv3;               // north-west, north-east, south-west, south-east
-        float pzz, pu, pv, pgx, pgy, wx1, wy1;   // what the warp's backward needs of the projection
-        bool vx1, vy1;
-        {
-            const Proj pr = md_project_r(cam[f], r0, r1, r2, depth, wm1, hm1, rw, rh);
-            const Clip c = clip_border(pr.ix, pr.iy, W, H);
-            const Tap t = md_make_tap(c.ix, c.iy, W, H);
-            vx1 = t.x0 + 1 < W; vy1 = t.y0 + 1 < H;
-            const int x1 = vx1 ? t.x0 + 1 : t.x0, y1 = vy1 ? t.y0 + 1 : t.y0;   // unconditional loads, see sample_border
-            pzz = pr.zz; pu = pr.u; pv = pr.v; pgx = c.gmx; pgy = c.gmy; wx1 = t.wx1; wy1 = t.wy1;
-            const float4 *im = reinterpret_cast<const float4 *>(a.src[f]) + (size_t)b * HW;
-            tv0 = im[t.y0 * W + t.x0]; tv1 = im[t.y0 * W + x1]; tv2 = im[y1 * W + t.x0]; tv3 = im[y1 * W + x1];
-            __builtin_amdgcn_sched_barrier(0);   // keep the loads up here: the scheduler otherwise sinks them to their first use
-        }
+        if (!(MD_PHOTO_BWD_EARLY & 1) && f == 0) cur = issue_taps(0);
+        if (!(MD_PHOTO_BWD_EARLY & 2) && f > 0) cur = issue_taps(f);
+        Taps nxt;
         // ---- coefficient maps at halo 1, only where frame f is the selected minimum and the mask is set
         if (use_ssim && !MD_PHOTO_BWD_ONEPASS) {
             coeff_phase(f);
@@ -502,65 +590,63 @@ __global__ __launch_bounds__(256, (F <= 2 ? MD_PHOTO_BWD_WAVES : 2)) void photo_
         float dP[12];
 #pragma unroll
         for (int k = 0; k < 12; ++k) dP[k] = 0.f;
+        bool has = false;   // does a gradient reach this pixel through frame f?
         if (qvalid) {
-            // ---- d loss / d pred_f[q][c]
-            float gA[3] = {0.f, 0.f, 0.f}, gB[3] = {0.f, 0.f, 0.f}, gC[3] = {0.f, 0.f, 0.f};
-            if (use_ssim) {
+            // ---- d loss / d pred_f[q][c]: (R, G) and (B, pad) halves of the coefficient records, two channels per instruction
+            v2f gA[2] = {(v2f)0.f, (v2f)0.f}, gB[2] = {(v2f)0.f, (v2f)0.f}, gC[2] = {(v2f)0.f, (v2f)0.f};
+            if (use_ssim && anyon[f]) {   // (a tile without a coefficient of this frame: masked out, or the other frame's everywhere)
+                const v4f *cfv = reinterpret_cast<const v4f *>(cf);
 #pragma unroll
-                for (int dy = -1; dy <= 1; ++dy) {
-                    const int py = qy + dy;
-                    if (py < 0 || py >= H) continue;
-                    // ReflectionPad2d adjoint: row 1 is also pad row -1 (seen by window row 0), row H-2 also pad row H
-                    const float wy = 1.f + ((qy == 1 && py == 0) ? 1.f : 0.f) + ((qy == H - 2 && py == H - 1) ? 1.f : 0.f);
+                for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-                    for (int dx = -1; dx <= 1; ++dx) {
-                        const int px = qx + dx;
-                        if (px < 0 || px >= W) continue;
-                        const float wx = 1.f + ((qx == 1 && px == 0) ? 1.f : 0.f) + ((qx == W - 2 && px == W - 1) ? 1.f : 0.f);
-                        const int o = (ty + 1 + dy) * B1_W + tx + 1 + dx;
-                        const float4 A = cf[o], Bc = cf[B1_N + o], Cc = cf[2 * B1_N + o];
-                        // (one-pass maps hold every frame's coefficients: those of the other frames contribute exact zeros, as the
-                        // zero-filled per-frame maps did)
-                        const float wgt = (!MD_PHOTO_BWD_ONEPASS || csel[o] == (signed char)f) ? wy * wx : 0.f;
-#pragma unroll
-                        for (int c = 0; c < 3; ++c) { gA[c] += wgt * f4c(A, c); gB[c] += wgt * f4c(Bc, c); gC[c] += wgt * f4c(Cc, c); }
+                    for (int dx = 0; dx < 3; ++dx) {
+                        const int o = (ty + dy) * B1_W + tx + dx;
+                        const v4f A = cfv[o], Bc = cfv[B1_N + o], Cc = cfv[2 * B1_N + o];
+                        // one-pass maps hold every frame's coefficients, the frame in A's pad lane: those of the other frames
+                        // contribute exact zeros, as the zero-filled per-frame maps did
+                        const v2f wgt = (v2f)((!MD_PHOTO_BWD_ONEPASS || A.w == (float)f) ? gwy[dy] * gwx[dx] : 0.f);
+                        gA[0] = md_fma(wgt, A.xy, gA[0]); gA[1] = md_fma(wgt, A.zw, gA[1]);
+                        gB[0] = md_fma(wgt, Bc.xy, gB[0]); gB[1] = md_fma(wgt, Bc.zw, gB[1]);
+                        gC[0] = md_fma(wgt, Cc.xy, gC[0]); gC[1] = md_fma(wgt, Cc.zw, gC[1]);
                     }
-                }
             }
-            const float4 xq4 = wf[(ty + 2) * B2_W + tx + 2], yq4 = tg[(ty + 2) * B2_W + tx + 2];
-            const float gl1 = (selq == (unsigned char)(0x80 | f)) ? gscale * maskq * wl1 / 3.f : 0.f;
-            float dpred[3];
+            const v4f xq4 = reinterpret_cast<const v4f *>(wf)[(ty + 2) * B2_W + tx + 2], yq4 = reinterpret_cast<const v4f *>(tg)[(ty + 2) * B2_W + tx + 2];
+            const float gl1 = (selq == (unsigned char)(0x80 | f)) ? gscale * maskq * wl1 * (1.f / 3.f) : 0.f;
+            v2f dpred[2];   // (R, G), (B, pad)
             bool any = false;
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const float xq = f4c(xq4, c), yq = f4c(yq4, c);
-                const float diff = yq - xq;
-                const float sg = diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f);
-                float g = -sg * gl1;
-                if (use_ssim) g += div9(gA[c] + 2.f * gB[c] * xq + gC[c] * yq);
-                dpred[c] = g;
-                any |= g != 0.f;
+            for (int h = 0; h < 2; ++h) {
+                const v2f xq = h ? xq4.zw : xq4.xy, yq = h ? yq4.zw : yq4.xy;
+                const v2f diff = yq - xq;
+                const v2f sg = {diff.x > 0.f ? 1.f : (diff.x < 0.f ? -1.f : 0.f), diff.y > 0.f ? 1.f : (diff.y < 0.f ? -1.f : 0.f)};
+                v2f g = -sg * gl1;
+                if (use_ssim) g += div9(gA[h] + 2.f * gB[h] * xq + gC[h] * yq);
+                dpred[h] = g;
+                any |= g.x != 0.f || (h == 0 && g.y != 0.f);
             }
             // ---- the warp's backward at q (warp.hip): gradients to the depth and to P = (K T)[:3]
+            has = any;
             if (any) {
-                const float wx0 = 1.f - wx1, wy0 = 1.f - wy1;
-                float gix = 0.f, giy = 0.f;
+                // A tap beyond the last column / row needs no select (see sample_border): there wx1 / wy1 is exactly 0 and the clip
+                // has zeroed the grid gradient of that axis, so the finite value read instead meets a zero factor either way.
+                const v4f tv0 = cur.t0, tv1 = cur.t1, tv2 = cur.t2, tv3 = cur.t3;
+                const float pzz = cur.pzz, wx1 = cur.wx1, wy1 = cur.wy1, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+                const v2f puv = cur.puv, pg = cur.pg;
+                v2f gxy = (v2f)0.f;   // (d / d ix, d / d iy)
 #pragma unroll
-                for (int ch = 0; ch < 3; ++ch) {
-                    const float nw = f4c(tv0, ch);
-                    const float ne = vx1 ? f4c(tv1, ch) : 0.f;
-                    const float sw = vy1 ? f4c(tv2, ch) : 0.f;
-                    const float se = (vx1 && vy1) ? f4c(tv3, ch) : 0.f;
-                    gix += dpred[ch] * ((ne - nw) * wy0 + (se - sw) * wy1);
-                    giy += dpred[ch] * ((sw - nw) * wx0 + (se - ne) * wx1);
+                for (int h = 0; h < 2; ++h) {
+                    const v2f nw = h ? tv0.zw : tv0.xy, ne = h ? tv1.zw : tv1.xy, sw = h ? tv2.zw : tv2.xy, se = h ? tv3.zw : tv3.xy;
+                    const v2f tx2 = (ne - nw) * wy0 + (se - sw) * wy1, ty2 = (sw - nw) * wx0 + (se - ne) * wx1;
+                    gxy = md_fma((v2f)dpred[h].x, (v2f){tx2.x, ty2.x}, gxy);
+                    if (h == 0) gxy = md_fma((v2f)dpred[h].y, (v2f){tx2.y, ty2.y}, gxy);
                 }
-                const float du = gix * pgx * (2.f / (float)(W - 1));
-                const float dv = giy * pgy * (2.f / (float)(H - 1));
-                const float dc0 = du / pzz, dc1 = dv / pzz, dc2 = -(du * pu + dv * pv) / pzz;
-                const float a0 = cam[f].P[0] * r0 + cam[f].P[1] * r1 + cam[f].P[2] * r2;
-                const float a1 = cam[f].P[4] * r0 + cam[f].P[5] * r1 + cam[f].P[6] * r2;
-                const float a2 = cam[f].P[8] * r0 + cam[f].P[9] * r1 + cam[f].P[10] * r2;
-                d_depth += dc0 * a0 + dc1 * a1 + dc2 * a2;
+                const v2f duv = gxy * pg * (2.f / wh1);
+                const float rzz = md_rcp_newton(pzz);   // a gradient: the reciprocal within an ulp serves three quotients
+                const v2f dc01 = duv * rzz;
+                const float dc0 = dc01.x, dc1 = dc01.y, dc2 = -(duv.x * puv.x + duv.y * puv.y) * rzz;
+                const v2f a01 = md_fma(cam[f].Pxy[2], (v2f)r2, md_fma(cam[f].Pxy[1], (v2f)r1, cam[f].Pxy[0] * r0));
+                const float a2 = cam[f].Pz[0] * r0 + cam[f].Pz[1] * r1 + cam[f].Pz[2] * r2;
+                d_depth += dc0 * a01.x + dc1 * a01.y + dc2 * a2;
                 if (a.d_T[f]) {
                     const float Xh[4] = {depth * r0, depth * r1, depth * r2, 1.f}, dc[3] = {dc0, dc1, dc2};
 #pragma unroll
@@ -575,14 +661,16 @@ __global__ __launch_bounds__(256, (F <= 2 ? MD_PHOTO_BWD_WAVES : 2)) void photo_
             // of the workgroup through LDS, summed in double by twelve threads (the terms cancel across image regions; as __shfl_xor
             // on doubles this was 288 LDS-crossbar instructions per wave and the kernel LDS-bound, as all-DPP double sums a
             // quarter of its VALU instructions)
+            const bool wave_has = __builtin_amdgcn_ballot_w64(has) != 0;   // a wave without a gradient sums twelve zeros: skip
 #pragma unroll
             for (int k = 0; k < 12; ++k) {
                 float v = dP[k];
 #define MD_DPP_ADDF(ctrl) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xF, 0xF, false))
-                MD_DPP_ADDF(0xB1); MD_DPP_ADDF(0x4E); MD_DPP_ADDF(0x141); MD_DPP_ADDF(0x140);
+                if (wave_has) { MD_DPP_ADDF(0xB1); MD_DPP_ADDF(0x4E); MD_DPP_ADDF(0x141); MD_DPP_ADDF(0x140); }
 #undef MD_DPP_ADDF
                 if ((lane & 15) == 0) redf[(wave * 4 + (lane >> 4)) * 12 + k] = v;
             }
+            if ((MD_PHOTO_BWD_EARLY & 2) && f + 1 < F) nxt = issue_taps(f + 1);   // behind the barriers and the next frame's LDS phase
             __syncthreads();
             if (tid < 12) {
                 double acc = 0.0;
@@ -591,10 +679,12 @@ __global__ __launch_bounds__(256, (F <= 2 ? MD_PHOTO_BWD_WAVES : 2)) void photo_
                 wsP[((((size_t)s * F + f) * a.B + b) * nblk + blk) * 12 + tid] = (float)acc;
             }
         }
+        else if ((MD_PHOTO_BWD_EARLY & 2) && f + 1 < F) nxt = issue_taps(f + 1);
         __syncthreads();  // cf / red are reused by the next frame
+        if ((MD_PHOTO_BWD_EARLY & 2) && f + 1 < F) cur = nxt;
     }
     if (qvalid) {
-        if (a.is_disp) gup[((size_t)s * a.B + b) * HW + q] = -d_depth * (max_disp - min_disp) / (sd * sd);  // d depth / d v = -(max-min)/sd^2
+        if (a.is_disp) gup[((size_t)s * a.B + b) * HW + q] = -d_depth * (max_disp - min_disp) * (depth * depth);  // d depth / d v = -(max-min)/sd^2, depth = 1/sd
         else a.d_dz[s][(size_t)b * HW + q] = d_depth;
     }
 }

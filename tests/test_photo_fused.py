@@ -190,6 +190,32 @@ def test_fused_matches_unfused_kernels_bitwise_where_shared(ops):
     assert torch.equal(out["warped"][0][0], warped)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("scale", [1.0, 255.0])
+def test_fused_loss_bit_equal_to_the_per_operation_kernels(ops, scale):
+    """The fused kernels form their quotients (depth = 1 / sd, cam.xy / z, SSIM n / d) as the steps of the IEEE division without
+    its range scaling, two per instruction (md_photo.hpp: md_div_core), and every sum on register pairs.  The per-operation
+    kernels (warp.hip, ssim.hip) divide with `/` and sum value by value: the per-pixel loss of one frame must carry the same BITS,
+    for images in [0, 1] and in [0, 255]."""
+    torch.manual_seed(1)
+    B, H, W = 2, 96, 160
+    target, s0 = scale * torch.rand(B, 3, H, W, device="cuda"), scale * torch.rand(B, 3, H, W, device="cuda")
+    Knp, invKnp = kitti_K(H, W, B)
+    K, invK = dev(Knp), dev(invKnp)
+    T = torch.eye(4, device="cuda").repeat(B, 1, 1)
+    T[:, 0, 3], T[:, 2, 3], T[:, 1, 3] = 0.08, -0.05, 0.01
+    disp = 0.01 + 0.5 * torch.rand(B, 1, H // 4, W // 4, device="cuda")
+    out = ops.photometric_loss(target, [s0], [T], K, invK, [disp], is_disp=True, want_pix=True)
+    depth = ops.disp_to_depth_up(disp, H, W, 0.1, 100.0)
+    warped, pix, _ = ops.warp_border(s0, depth, K, invK, T, want_pix=True)
+    assert torch.equal(out["depth"][0], depth)
+    assert torch.equal(out["pix"][0][0], pix)
+    assert torch.equal(out["warped"][0][0], warped)
+    per_op = ops.reprojection_loss(warped, target)
+    fused = out["min"][0].reshape(per_op.shape)
+    assert torch.equal(fused, per_op), "max |diff| %.3e" % (fused - per_op).abs().max().item()
+
+
 def test_mono_chain_bit_equal_to_the_reference_fixture(ops):
     """tests/golden/losses_mono.npz holds what the reference Trainer's own generate_images_pred (trainer.py:510-532) produced:
     the depth of every pyramid level, the sample grid and the warped frames.  The fused kernel evaluates F.interpolate's taps,
