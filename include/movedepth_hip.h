@@ -198,7 +198,10 @@ int md_masked_min_bwd(const float *gloss, const float *reproj, const float *mask
  * md_reproj_loss / md_masked_min above, which remain for callers that want the pieces.
  *
  * All images PACKED, [B,H,W,4] float (r, g, b, 0 per pixel: md_pack_rgbx converts [B,3,H,W] frames): target, src[f] and the
- * warped[s][f] outputs; maps [B,H,W] (= [B,1,H,W]); K, invK, T[f] [B,4,4].  NULL output pointers are skipped. */
+ * warped[s][f] outputs; maps [B,H,W] (= [B,1,H,W]); K, invK, T[f] [B,4,4].  NULL output pointers are skipped.
+ * Domain of the bit-equality with those pieces: finite pixel values of magnitude below 2^20 (images in [0,1] or [0,255]) and a
+ * depth range inside [2^-40, 2^40] -- the fused kernels form their quotients as the steps of the IEEE division without its range
+ * scaling (csrc/md_photo.hpp), which is the identity there. */
 #define MD_PHOTO_MAX_FRAMES 4
 #define MD_PHOTO_MAX_SCALES 4
 typedef struct md_photo_desc {

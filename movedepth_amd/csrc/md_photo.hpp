@@ -75,6 +75,16 @@ __device__ __forceinline__ float interp4(float nw, float ne, float sw, float se,
 }
 
 // upsampled disparity at (y, x) of the full-resolution grid -> scaled disparity sd (depth = 1 / sd, layers.py:400-409)
+// (sx = (float)w / (float)W, sy = (float)h / (float)H: IEEE quotients of launch constants, formed once on the host)
+__device__ __forceinline__ float disp_up_sd_s(const float *__restrict__ s, int h, int w, float sy, float sx, int y, int x, float min_disp,
+                                              float max_disp) {
+#pragma clang fp contract(off)
+    int x0, x1, y0, y1;
+    float lx, ly;
+    interp_idx_s(x, w, sx, x0, x1, lx);
+    interp_idx_s(y, h, sy, y0, y1, ly);
+    return min_disp + (max_disp - min_disp) * interp4(s[y0 * w + x0], s[y0 * w + x1], s[y1 * w + x0], s[y1 * w + x1], lx, ly);
+}
 __device__ __forceinline__ float disp_up_sd(const float *__restrict__ s, int h, int w, int H, int W, int y, int x,
                                             float min_disp, float max_disp) {
     // no contraction: the oracle's (mdo_resize_bilinear_fwd, mdo_disp_to_depth) operations one by one -- the depth feeds the

@@ -56,6 +56,24 @@ constexpr int BT_W = 32, BT_H = 8;                                              
 constexpr int B2_W = BT_W + 4, B2_H = BT_H + 4, B2_N = B2_W * B2_H;                        // + halo 2 (images)
 constexpr int B1_W = BT_W + 2, B1_H = BT_H + 2, B1_N = B1_W * B1_H;                        // + halo 1 (coefficients)
 
+// Quotients of launch constants every thread would otherwise form with a 12-instruction IEEE division each (7 per thread: 4 % of the
+// backward's vector instructions): formed once on the host, in float -- the same correctly rounded values.
+struct PhotoConsts {
+    float min_disp, max_disp;     // 1 / max_depth, 1 / min_depth
+    float rw, rh;                 // 1 / (W - 1), 1 / (H - 1)
+    float upx[MAXS], upy[MAXS];   // dw[s] / W, dh[s] / H: F.interpolate's scales
+};
+inline PhotoConsts photo_consts(const md_photo_desc *d) {
+    PhotoConsts k{};
+    k.min_disp = 1.f / d->max_depth; k.max_disp = 1.f / d->min_depth;
+    k.rw = 1.f / (float)(d->W - 1); k.rh = 1.f / (float)(d->H - 1);
+    for (int s = 0; s < MAXS; ++s) {
+        k.upx[s] = d->is_disp && s < d->S ? (float)d->dw[s] / (float)d->W : 0.f;
+        k.upy[s] = d->is_disp && s < d->S ? (float)d->dh[s] / (float)d->H : 0.f;
+    }
+    return k;
+}
+
 __device__ __forceinline__ float f4c(const float4 &v, int c) { return c == 0 ? v.x : (c == 1 ? v.y : v.z); }
 
 // The four records of a bilinear footprint, from clamped addresses: one 32-bit byte offset from the image's (wave-uniform) base
@@ -144,8 +162,9 @@ template <int F>
 __device__ __forceinline__ void load_cams_pk(const md_photo_desc &a, int b, float *camS, CamPk (&cam)[F], float (&iK)[9]) {
     load_cams_lds<F>(a, b, camS);
     // the matrices are the same in every lane: v_readfirstlane_b32 moves them to scalar registers, which the vector instructions
-    // read directly (12 F + 9 vector registers less: what lets the backward keep a frame's taps in flight, see issue_taps)
-    auto uni = [](float v) { return MD_PHOTO_CAM_SGPR ? __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))) : v; };
+    // read directly (12 F + 9 vector registers less: what lets the backward keep a frame's taps in flight, see issue_taps); up to
+    // two frames -- beyond, the scalar file is what runs out, and those kernels have vector registers to spare
+    auto uni = [](float v) { return (MD_PHOTO_CAM_SGPR && F <= 2) ? __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))) : v; };
 #pragma unroll
     for (int f = 0; f < F; ++f)
 #pragma unroll
@@ -159,7 +178,7 @@ __device__ __forceinline__ void load_cams_pk(const md_photo_desc &a, int b, floa
 
 // ------------------------------------------------------------------------------------------------ forward
 template <int F, bool IDENT>
-__global__ __launch_bounds__(256, (F <= 2 ? MD_PHOTO_FWD_WAVES : 2)) void photo_fwd_kernel(const md_photo_desc a, float *__restrict__ ws) {
+__global__ __launch_bounds__(256, (F <= 2 ? MD_PHOTO_FWD_WAVES : 2)) void photo_fwd_kernel(const md_photo_desc a, const PhotoConsts kc, float *__restrict__ ws) {
     extern __shared__ float4 lds[];
     float4 *tg = lds;          // target, halo 1
     float4 *wp = lds + FP_N;   // wp[f * FP_N + i]: prediction of frame f
@@ -177,8 +196,8 @@ __global__ __launch_bounds__(256, (F <= 2 ? MD_PHOTO_FWD_WAVES : 2)) void photo_
     if (!IDENT) load_cams_pk<F>(a, b, camS, cam, iK);
     const size_t HW = (size_t)H * W;
     const float4 *tgt = reinterpret_cast<const float4 *>(a.target) + (size_t)b * HW;
-    const float min_disp = 1.f / a.max_depth, max_disp = 1.f / a.min_depth;
-    const v2f wh1 = {(float)(W - 1), (float)(H - 1)}, rwh = {1.f / wh1.x, 1.f / wh1.y};
+    const float min_disp = kc.min_disp, max_disp = kc.max_disp;
+    const v2f wh1 = {(float)(W - 1), (float)(H - 1)}, rwh = {kc.rw, kc.rh};
 
     // ---- phase 1: every halo position -> target + F predictions in LDS.  Unrolled: the loads of a thread's (up to) three
     // positions are independent and should all be in flight together -- the kernel is bound by memory latency, not bandwidth
@@ -197,7 +216,7 @@ __global__ __launch_bounds__(256, (F <= 2 ? MD_PHOTO_FWD_WAVES : 2)) void photo_
             const bool own = cy >= 1 && cy <= FT_H && cx >= 1 && cx <= FT_W && gy < H && gx < W;
             float depth;
             if (a.is_disp) {
-                const float sd = disp_up_sd(a.dz[s] + (size_t)b * a.dh[s] * a.dw[s], a.dh[s], a.dw[s], H, W, py, px, min_disp, max_disp);
+                const float sd = disp_up_sd_s(a.dz[s] + (size_t)b * a.dh[s] * a.dw[s], a.dh[s], a.dw[s], kc.upy[s], kc.upx[s], py, px, min_disp, max_disp);
 #if MD_PHOTO_FAST_DIV
                 depth = md_div_fixup(md_div_core(1.f, sd, md_rcp_newton(sd)), sd, 1.f);   // sd in [1 / max_depth, 1 / min_depth]
 #else
@@ -386,7 +405,7 @@ __global__ __launch_bounds__(256) void photo_fwd_finish_kernel(const float *__re
 // ------------------------------------------------------------------------------------------------ backward
 // three waves per SIMD (<= 168 registers) for up to two source frames, two beyond
 template <int F>
-__global__ __launch_bounds__(256, (F <= 2 ? MD_PHOTO_BWD_WAVES : 2)) void photo_bwd_kernel(const md_photo_desc a, float *__restrict__ gup, float *__restrict__ wsP) {
+__global__ __launch_bounds__(256, (F <= 2 ? MD_PHOTO_BWD_WAVES : 2)) void photo_bwd_kernel(const md_photo_desc a, const PhotoConsts kc, float *__restrict__ gup, float *__restrict__ wsP) {
     extern __shared__ float4 lds[];
     float4 *tg = lds;                         // target, halo 2
     float4 *wp = lds + B2_N;                  // wp[f * B2_N + i]: warped frame f, halo 2
@@ -402,8 +421,8 @@ __global__ __launch_bounds__(256, (F <= 2 ? MD_PHOTO_BWD_WAVES : 2)) void photo_
     const int b = item / nblk, blk = item % nblk;
     const int x0 = (blk % tiles_x) * BT_W, y0 = (blk / tiles_x) * BT_H;
     const size_t HW = (size_t)H * W;
-    const float min_disp = 1.f / a.max_depth, max_disp = 1.f / a.min_depth;
-    const v2f wh1 = {(float)(W - 1), (float)(H - 1)}, rwh = {1.f / wh1.x, 1.f / wh1.y};
+    const float min_disp = kc.min_disp, max_disp = kc.max_disp;
+    const v2f wh1 = {(float)(W - 1), (float)(H - 1)}, rwh = {kc.rw, kc.rh};
     const bool use_ssim = !a.no_ssim && a.ssim_w != 0.f;
     const float wl1 = a.no_ssim ? 1.f : (1.f - a.ssim_w);
     // d loss_s / d (min * mask)[p] = gloss_s / (sum(mask) + 1e-7)
@@ -455,7 +474,7 @@ __global__ __launch_bounds__(256, (F <= 2 ? MD_PHOTO_BWD_WAVES : 2)) void photo_
     {
         const int cqy = qvalid ? qy : 0, cqx = qvalid ? qx : 0;
         if (a.is_disp) {
-            sd = disp_up_sd(a.dz[s] + (size_t)b * a.dh[s] * a.dw[s], a.dh[s], a.dw[s], H, W, cqy, cqx, min_disp, max_disp);
+            sd = disp_up_sd_s(a.dz[s] + (size_t)b * a.dh[s] * a.dw[s], a.dh[s], a.dw[s], kc.upy[s], kc.upx[s], cqy, cqx, min_disp, max_disp);
 #if MD_PHOTO_FAST_DIV
             depth = md_div_fixup(md_div_core(1.f, sd, md_rcp_newton(sd)), sd, 1.f);   // the forward's bits: the same taps
 #else
@@ -762,24 +781,31 @@ __global__ __launch_bounds__(256) void up_adjoint_kernel(const md_photo_desc a, 
         const int n = (h == H && w == W) ? 0 : fw * (oy_hi - oy_lo + 1);
         if (n == 0) acc = g[(size_t)iy * W + ix];
         const int side = lpp >= 64 ? 8 : (lpp >= 16 ? 4 : (lpp >= 4 ? 2 : 1));   // the pixel's lanes as a side x side grid
-        if (n > 0 && exact && side * side == lpp) {
+        constexpr int NC = 5;   // window columns per lane the fast path holds weights for
+        if (n > 0 && exact && side * side == lpp && fw <= side * NC) {
             // lane (sub / side, sub % side) takes window rows sub_y + side * j and columns sub_x + side * i: no division by the
-            // window width per element, and a row's / column's weight is formed once (the index arithmetic of the flat loop
-            // below was 70 instructions per element: 28 us of the kernel's 42)
+            // window width per element (the index arithmetic of the flat loop below was 70 instructions per element: 28 us of the
+            // kernel's 42), and the weights are separable: a column's is formed once per lane, a row's once per row -- formed per
+            // element they were 15 of an element's 25 instructions
             const int sub_y = sub / side, sub_x = sub % side;
             const int fh = oy_hi - oy_lo + 1;
+            float wxk[NC];
+#pragma unroll
+            for (int k = 0; k < NC; ++k) {
+                const int ox = ox_lo + sub_x + side * k;
+                int x0, x1; float lx;
+                interp_idx_s(ox < W ? ox : W - 1, w, sx, x0, x1, lx);
+                wxk[k] = ox < ox_lo + fw ? (x0 == ix ? 1.f - lx : 0.f) + (x1 == ix ? lx : 0.f) : 0.f;
+            }
             for (int oy = oy_lo + sub_y; oy < oy_lo + fh; oy += side) {
                 int y0, y1; float ly;
                 interp_idx_s(oy, h, sy, y0, y1, ly);
                 const float wy = (y0 == iy ? 1.f - ly : 0.f) + (y1 == iy ? ly : 0.f);
                 if (wy == 0.f) continue;   // (uniform over most of the wave: whole window rows fall outside the pixel's support)
-                for (int ox = ox_lo + sub_x; ox < ox_lo + fw; ox += side) {
-                    const float gv = g[(size_t)oy * W + ox];
-                    int x0, x1; float lx;
-                    interp_idx_s(ox, w, sx, x0, x1, lx);
-                    const float wx = (x0 == ix ? 1.f - lx : 0.f) + (x1 == ix ? lx : 0.f);
-                    if (wx != 0.f) acc += gv * wy * wx;
-                }
+                const float *grow = g + (size_t)oy * W + ox_lo + sub_x;
+#pragma unroll
+                for (int k = 0; k < NC; ++k)
+                    if (wxk[k] != 0.f) acc += grow[side * k] * wy * wxk[k];
             }
         } else {
         // (non-integer ratios) no early `continue`: the loads stay unconditional
@@ -874,10 +900,11 @@ extern "C" int md_photo_fwd(const md_photo_desc *d, void *ws, md_stream_t stream
     dim3 grid(photo_grid(d->B * tiles, S));
     const size_t lds = sizeof(float4) * (size_t)(1 + F) * FP_N;
     hipStream_t st = (hipStream_t)stream;
+    const PhotoConsts kc = photo_consts(d);
 #define MD_PH_FWD(F_)                                                                                                       \
     do {                                                                                                                    \
-        if (d->identity) MD_LAUNCH_TIMED("md_photo_fwd", (photo_fwd_kernel<F_, true>), grid, dim3(256), lds, st, *d, (float *)ws); \
-        else MD_LAUNCH_TIMED("md_photo_fwd", (photo_fwd_kernel<F_, false>), grid, dim3(256), lds, st, *d, (float *)ws);     \
+        if (d->identity) MD_LAUNCH_TIMED("md_photo_fwd", (photo_fwd_kernel<F_, true>), grid, dim3(256), lds, st, *d, kc, (float *)ws); \
+        else MD_LAUNCH_TIMED("md_photo_fwd", (photo_fwd_kernel<F_, false>), grid, dim3(256), lds, st, *d, kc, (float *)ws); \
     } while (0)
     if (F == 1) MD_PH_FWD(1); else if (F == 2) MD_PH_FWD(2); else if (F == 3) MD_PH_FWD(3); else MD_PH_FWD(4);
 #undef MD_PH_FWD
@@ -910,10 +937,11 @@ extern "C" int md_photo_bwd(const md_photo_desc *d, void *ws, md_stream_t stream
     float *gup = wsP + (size_t)12 * d->S * F * d->B * nblk;
     const size_t lds = sizeof(float4) * ((size_t)(1 + F) * B2_N + 3 * B1_N);
     hipStream_t st = (hipStream_t)stream;
-    if (F == 1) MD_LAUNCH_TIMED("md_photo_bwd", (photo_bwd_kernel<1>), grid, dim3(256), lds, st, *d, gup, wsP);
-    else if (F == 2) MD_LAUNCH_TIMED("md_photo_bwd", (photo_bwd_kernel<2>), grid, dim3(256), lds, st, *d, gup, wsP);
-    else if (F == 3) MD_LAUNCH_TIMED("md_photo_bwd", (photo_bwd_kernel<3>), grid, dim3(256), lds, st, *d, gup, wsP);
-    else MD_LAUNCH_TIMED("md_photo_bwd", (photo_bwd_kernel<4>), grid, dim3(256), lds, st, *d, gup, wsP);
+    const PhotoConsts kc = photo_consts(d);
+    if (F == 1) MD_LAUNCH_TIMED("md_photo_bwd", (photo_bwd_kernel<1>), grid, dim3(256), lds, st, *d, kc, gup, wsP);
+    else if (F == 2) MD_LAUNCH_TIMED("md_photo_bwd", (photo_bwd_kernel<2>), grid, dim3(256), lds, st, *d, kc, gup, wsP);
+    else if (F == 3) MD_LAUNCH_TIMED("md_photo_bwd", (photo_bwd_kernel<3>), grid, dim3(256), lds, st, *d, kc, gup, wsP);
+    else MD_LAUNCH_TIMED("md_photo_bwd", (photo_bwd_kernel<4>), grid, dim3(256), lds, st, *d, kc, gup, wsP);
     MD_CHECK_LAUNCH("md_photo_bwd");
     bool any_T = false;
     for (int f = 0; f < F; ++f) any_T |= d->d_T[f] != nullptr;
