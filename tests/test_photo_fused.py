@@ -89,7 +89,7 @@ def run_fused(ops, target, srcs, Ts, K, invK, zs, gl, T_grad=True, **kw):
     return out, tz, tT
 
 
-@pytest.mark.parametrize("B,H,W,F,S", [(2, 64, 96, 2, 4), (1, 37, 71, 1, 2), (2, 48, 80, 3, 3), (2, 192, 640, 2, 4), (6, 192, 640, 2, 4)])
+@pytest.mark.parametrize("B,H,W,F,S", [(2, 64, 96, 2, 4), (1, 37, 71, 1, 2), (2, 48, 80, 3, 3), (1, 40, 72, 4, 1), (2, 192, 640, 2, 4), (6, 192, 640, 2, 4)])
 def test_mono_all_scales_vs_oracle(ops, oracle_lib, B, H, W, F, S):
     """trainer.py:510-532 + 675-709: disparity pyramid, auto-mask against the identity loss with per-scale noise.
     (6, 192, 640, 2, 4) is the launch the bench runs (BASELINE config 2): the kernels' (sample, tile) -> XCD item order depends
@@ -117,7 +117,7 @@ def test_mono_all_scales_vs_oracle(ops, oracle_lib, B, H, W, F, S):
         flips = int((host(out["mask"][s]) != exp["mask"]).sum())
         assert flips == 0, "auto-mask differs at %d pixels" % flips
         share = np.bincount(exp["reproj"].argmin(1).ravel(), minlength=F) / exp["mn"].size
-        assert share.min() > 0.03 and 0.02 < exp["mask"].mean() < 0.98, (share, exp["mask"].mean())   # every branch exercised
+        assert share.min() > (0.03 if F <= 3 else 0.01) and 0.02 < exp["mask"].mean() < 0.98, (share, exp["mask"].mean())   # every branch exercised
         assert abs(float(out["loss"][s].detach()) - exp["loss"]) <= 1e-4 * abs(exp["loss"]), (s, float(out["loss"][s].detach()), exp["loss"])
         # a disparity pixel of level s gathers 4^s full-resolution samples: the share of pixels touched by a sample that sits on
         # a texel boundary (assert_close_knife_edge) grows with the level
