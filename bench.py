@@ -432,8 +432,8 @@ def main():
     # the photometric groups against memory: ALGORITHMIC bytes per step (the mono group's forward reads 54 MB and writes
     # 168 MB -- 8 warped frames, 8 sample grids, 4 depths -- = 222 MB, its backward 148 MB; a one-scale group (MVS, fused depth) 74 MB forward;
     # the identity loss 38 MB; the one-scale backwards pro rata) over the entry point's kernel time in the step.  These kernels are not
-    # memory-bound -- the vector ALU is the busiest unit (~70 % of the cycles; 14-28 % of HBM): the counters are in
-    # profiles/r06_photo_pmc.txt -- the figure is here because the roofline of every hot-path kernel is asked for.
+    # memory-bound -- the vector ALU is the busiest unit (~52 % of the cycles beside the per-pixel gathers; 13-27 % of HBM): the counters
+    # are in profiles/r06_photo_pmc.txt -- the figure is here because the roofline of every hot-path kernel is asked for.
     if not a.trainer_args and opt.height == 192 and opt.width == 640 and opt.batch_size == 6:
         for k_, nbytes in (("md_photo_fwd", 222e6 + 2 * 74e6 + 38e6), ("md_photo_bwd", 148e6 + 2 * 74e6 * 148.0 / 222.0)):
             if k_ in photo_in_step:
@@ -441,7 +441,7 @@ def main():
                 e_["algorithmic_bytes_per_step"] = nbytes
                 e_["achieved_gbs"] = nbytes / e_["us_per_step"] * 1e-3
                 e_["frac_of_hbm_peak"] = e_["achieved_gbs"] / HBM_PEAK_GBS
-                e_["bound"] = "vector ALU (profiles/r06_photo_pmc.txt), not HBM"
+                e_["bound"] = "vector ALU ~52 % busy + per-pixel gathers (profiles/r06_photo_pmc.txt), not HBM"
     if os.environ.get("MD_BENCH_DUMP_TIMES"):
         for k_ in ("md_costvol_fwd" + sfx, "md_costvol_bwd" + sfx):
             print(k_, " ".join("%.0f" % t for t in times.get(k_, {}).get("all_us", [])), file=sys.stderr)
