@@ -110,6 +110,10 @@ class MonodepthOptions:
         p.add_argument("--fused_photometric", type=int, default=1,
                        help="generate_images_pred + compute_losses' photometric part as one kernel launch each way per group of "
                             "losses (csrc/photo.hip); 0: one kernel per warp / loss / reduction, as in round 2")
+        p.add_argument("--lazy_sample_grids", type=int, default=1,
+                       help="with --fused_photometric: outputs[(\"sample\", f, s)] -- which nothing on the training path reads "
+                            "(reference trainer.py:524-529 only hands it to grid_sample) -- is computed when first accessed "
+                            "instead of being stored by every step (8 maps, 47 MB per step at config 2); the same bits either way")
         p.add_argument("--amp", default="none", choices=["none", "bf16", "fp16"],
                        help="mixed precision (BASELINE configs 4 / 5): networks under autocast, 2-byte cost volume; the "
                             "headline bench is fp32")

@@ -53,6 +53,31 @@ def build_models(opt, num_pose_frames=2):
     return models, main, mvs
 
 
+class StepOutputs(dict):
+    """The `outputs` dictionary of process_batch.  An entry registered with lazy() is produced when first accessed: `key in
+    outputs` and `outputs[key]` behave as if it were stored; keys() / items() list it only once it has been."""
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self._lazy = {}
+
+    def lazy(self, key, fn):
+        self._lazy[key] = fn
+
+    def __missing__(self, key):
+        fn = self._lazy.pop(key, None)
+        if fn is None:
+            raise KeyError(key)
+        value = self[key] = fn()
+        return value
+
+    def __contains__(self, key):
+        return dict.__contains__(self, key) or key in self._lazy
+
+    def get(self, key, default=None):
+        return self[key] if key in self else default
+
+
 class Trainer:
     def __init__(self, options):
         self.opt = options
@@ -282,7 +307,7 @@ class Trainer:
         for key, ipt in inputs.items():
             if torch.is_tensor(ipt):     # (private entries of an earlier call on the same dictionary are not tensors)
                 inputs[key] = ipt.to(self.device, non_blocking=True)
-        outputs = {}
+        outputs = StepOutputs()
         if not opt.load_pose:
             outputs.update(self.predict_poses(inputs, None))
         else:
@@ -451,13 +476,21 @@ class Trainer:
         if not opt.disable_automasking:
             ident = ops.identity_loss(target, srcs, opt.ssim_lw, opt.no_ssim)
             noise = self._automask_noise((B, 1, H, W), len(opt.scales))   # one draw per scale, in the reference's order
+        lazy = bool(getattr(opt, "lazy_sample_grids", 0)) and isinstance(outputs, StepOutputs)
         res = ops.photometric_loss(target, srcs, [outputs[("cam_T_cam", 0, f)] for f in frames], K, inv_K,
                                    [outputs[("disp", s)] for s in opt.scales], is_disp=True, ident_min=ident, noise=noise,
-                                   want_pix=True, **common)
+                                   want_pix=not lazy, **common)
         for si, scale in enumerate(opt.scales):
             outputs[("depth", 0, scale)] = res["depth"][si]
             for i, f in enumerate(frames):
-                outputs[("sample", f, scale)] = res["pix"][si][i]
+                if lazy:   # the per-operation warp evaluates the same arithmetic: the same bits (tests/test_photo_fused.py)
+                    def grid(f=f, scale=scale):
+                        with torch.no_grad():
+                            return ops.warp_border(inputs[("color", f, 0)], outputs[("depth", 0, scale)].detach(), K, inv_K,
+                                                   outputs[("cam_T_cam", 0, f)].detach(), want_pix=True)[1]
+                    outputs.lazy(("sample", f, scale), grid)
+                else:
+                    outputs[("sample", f, scale)] = res["pix"][si][i]
                 outputs[("color", f, scale)] = res["warped"][si][i]
                 outputs[("color_identity", f, scale)] = inputs[("color", f, 0)]
         outputs[("_photo", "mono")] = res

@@ -42,3 +42,24 @@ def test_census_word_decoding():
     g, t, w, s = 12_345 * 4, 69_120, 929, 720
     word = np.array([((g // 4) << 46) | ((t // 4) << 28) | (w << 14) | s], dtype=np.uint64)
     assert BackwardPolicy._census(word) == (g, t, w, s)
+
+
+def test_step_outputs_lazy_entries():
+    """trainer.StepOutputs: an entry registered with lazy() behaves as stored (`in`, [], get) and is produced once."""
+    from movedepth_amd.trainer import StepOutputs
+
+    calls = []
+    o = StepOutputs()
+    o["a"] = 1
+    o.update({"b": 2})
+    o.lazy(("sample", -1, 0), lambda: calls.append(1) or 42)
+    assert "a" in o and ("sample", -1, 0) in o and "c" not in o
+    assert ("sample", -1, 0) not in list(o.keys())
+    assert o[("sample", -1, 0)] == 42 and o[("sample", -1, 0)] == 42 and calls == [1]
+    assert ("sample", -1, 0) in list(o.keys())
+    assert o.get("c") is None and o.get("b") == 2
+    try:
+        o["c"]
+        raise AssertionError("missing key must raise")
+    except KeyError:
+        pass

@@ -225,6 +225,41 @@ def test_mvs_and_fuse_losses_fullres_match_reference(fused):
         assert_close_knife_edge(dd[..., ::4, ::8], g[name + "_lattice"], rtol=2e-4, what=name + " lattice")
 
 
+def test_lazy_sample_grids_are_the_eager_ones():
+    """--lazy_sample_grids 1 (default): outputs[("sample", f, s)] is formed on first access by the per-operation warp; with 0 the
+    fused forward stores it every step.  The same bits: the grids a step hands out lazily against the ones the fused forward
+    stores for the same disparities and poses."""
+    from movedepth_amd import ops
+    from movedepth_amd.options import MovedepthOptions
+    from movedepth_amd.synthetic import make_inputs
+    from movedepth_amd.trainer import StepOutputs, Trainer
+
+    for lazy in (0, 1):
+        opt = MovedepthOptions().parse(["--height", "64", "--width", "128", "--num_depth_bins", "16", "--batch_size", "2",
+                                        "--weights_init", "scratch", "--miopen_find", "0", "--lazy_sample_grids", str(lazy)])
+        torch.manual_seed(0)
+        np.random.seed(0)
+        t = Trainer(opt)
+        t.set_train()
+        inputs = make_inputs(2, 64, 128, opt.frame_ids, seed=0, device=t.device)
+        outputs, losses = t.process_batch(inputs, is_train=True)
+        assert isinstance(outputs, StepOutputs) and torch.isfinite(losses["loss"])
+        assert ("sample", -1, 0) in outputs and ("sample", 1, 3) in outputs
+        stored = dict.__contains__(outputs, ("sample", -1, 0))
+        assert stored == (not lazy), "lazy=%d but the grid was %s by the step" % (lazy, "stored" if stored else "not stored")
+        frames = opt.frame_ids[1:]
+        target, srcs = t._packed_frames(inputs)
+        with torch.no_grad():
+            res = ops.photometric_loss(target, srcs, [outputs[("cam_T_cam", 0, f)].detach() for f in frames], inputs[("K", 0)],
+                                       inputs[("inv_K", 0)], [outputs[("disp", s)].detach() for s in opt.scales], is_disp=True,
+                                       min_depth=opt.min_depth, max_depth=opt.max_depth, want_pix=True)
+        for si, s_ in enumerate(opt.scales):
+            for i, f in enumerate(frames):
+                got = outputs[("sample", f, s_)]
+                assert got.shape == res["pix"][si][i].shape and torch.equal(got, res["pix"][si][i]), (lazy, f, s_)
+        assert dict.__contains__(outputs, ("sample", -1, 0))   # stored once accessed
+
+
 def test_process_batch_runs_and_has_reference_keys():
     """End-to-end step at BASELINE config 1 shape (64x128, D=16, B=1): output / loss keys of the reference
      are present, the loss is finite and every parameter receives a finite gradient."""

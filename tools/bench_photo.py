@@ -52,7 +52,7 @@ def main():
 
     def mono(bwd):
         ident = ops.identity_loss(target, srcs)
-        out = ops.photometric_loss(target, srcs, Ts, K, invK, disps, is_disp=True, ident_min=ident, noise=noise, want_pix=True)
+        out = ops.photometric_loss(target, srcs, Ts, K, invK, disps, is_disp=True, ident_min=ident, noise=noise, want_pix=bool(int(os.environ.get("WANT_PIX", "1"))))
         if bwd:
             sum(out["loss"]).backward()
 
