@@ -703,7 +703,12 @@ __global__ __launch_bounds__(256, (F <= 2 ? MD_PHOTO_BWD_WAVES : 2)) void photo_
         if ((MD_PHOTO_BWD_EARLY & 2) && f + 1 < F) cur = nxt;
     }
     if (qvalid) {
-        if (a.is_disp) gup[((size_t)s * a.B + b) * HW + q] = -d_depth * (max_disp - min_disp) * (depth * depth);  // d depth / d v = -(max-min)/sd^2, depth = 1/sd
+        if (a.is_disp) {
+            const float gv = -d_depth * (max_disp - min_disp) * (depth * depth);   // d depth / d v = -(max-min)/sd^2, depth = 1/sd
+            // a level of the image's own size is up-sampled by the identity: its gradient is final here (up_adjoint_kernel skips it)
+            if (a.dh[s] == H && a.dw[s] == W) a.d_dz[s][(size_t)b * HW + q] = gv;
+            else gup[((size_t)s * a.B + b) * HW + q] = gv;
+        }
         else a.d_dz[s][(size_t)b * HW + q] = d_depth;
     }
 }
@@ -749,6 +754,7 @@ __global__ __launch_bounds__(256) void photo_bwd_finish_kernel(const md_photo_de
 __global__ __launch_bounds__(256) void up_adjoint_kernel(const md_photo_desc a, const float *__restrict__ gup) {
     const int s = blockIdx.y;
     const int h = a.dh[s], w = a.dw[s], H = a.H, W = a.W;
+    if (h == H && w == W) return;   // written by photo_bwd_kernel itself
     const int ry = (H + h - 1) / h, rx = (W + w - 1) / w;
     int lpp = ry * rx;
     lpp = lpp >= 64 ? 64 : (lpp >= 16 ? 16 : (lpp >= 4 ? 4 : 1));
@@ -952,13 +958,16 @@ extern "C" int md_photo_bwd(const md_photo_desc *d, void *ws, md_stream_t stream
     if (d->is_disp) {
         long long mx = 0;
         for (int s = 0; s < d->S; ++s) {
+            if (d->dh[s] == d->H && d->dw[s] == d->W) continue;   // photo_bwd_kernel wrote d_dz[s] itself
             int lpp = md_cdiv(d->H, d->dh[s]) * md_cdiv(d->W, d->dw[s]);
             lpp = lpp >= 64 ? 64 : (lpp >= 16 ? 16 : (lpp >= 4 ? 4 : 1));
             const long long n = (long long)d->B * d->dh[s] * d->dw[s] * lpp;
             mx = n > mx ? n : mx;
         }
-        MD_LAUNCH_TIMED("md_photo_bwd", up_adjoint_kernel, dim3((unsigned)md_cdiv(mx, 256), d->S), dim3(256), 0, st, *d, (const float *)gup);
-        MD_CHECK_LAUNCH("md_photo_bwd(up-sampling adjoint)");
+        if (mx > 0) {
+            MD_LAUNCH_TIMED("md_photo_bwd", up_adjoint_kernel, dim3((unsigned)md_cdiv(mx, 256), d->S), dim3(256), 0, st, *d, (const float *)gup);
+            MD_CHECK_LAUNCH("md_photo_bwd(up-sampling adjoint)");
+        }
     }
     return MD_OK;
 }
