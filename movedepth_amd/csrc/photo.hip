@@ -856,6 +856,7 @@ int check_desc(const char *fn, const md_photo_desc *d) {
     MD_REQUIRE(d, "%s: null descriptor", fn);
     MD_REQUIRE(d->B > 0 && d->B <= 4096 && d->H >= 3 && d->W >= 3, "%s: bad dims B=%d H=%d W=%d (H, W >= 3)", fn, d->B, d->H, d->W);
     MD_REQUIRE(d->F >= 1 && d->F <= MAXF && d->S >= 1 && d->S <= MAXS, "%s: F=%d (1..%d), S=%d (1..%d)", fn, d->F, MAXF, d->S, MAXS);
+    MD_REQUIRE((long long)d->H * d->W < (1ll << 27), "%s: %d x %d: an image of 2^27 pixels or more (32-bit byte offsets into a packed frame)", fn, d->H, d->W);
         MD_REQUIRE(d->target, "%s: null target", fn);
     for (int f = 0; f < d->F; ++f) MD_REQUIRE(d->src[f], "%s: null src[%d]", fn, f);
     if (!d->identity) {
