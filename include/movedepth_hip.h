@@ -201,7 +201,7 @@ int md_masked_min_bwd(const float *gloss, const float *reproj, const float *mask
  * warped[s][f] outputs; maps [B,H,W] (= [B,1,H,W]); K, invK, T[f] [B,4,4].  NULL output pointers are skipped.
  * Domain of the bit-equality with those pieces: finite pixel values of magnitude below 2^20 (images in [0,1] or [0,255]) and a
  * depth range inside [2^-40, 2^40] -- the fused kernels form their quotients as the steps of the IEEE division without its range
- * scaling (csrc/md_photo.hpp), which is the identity there. */
+ * scaling (csrc/md_photo.hpp), which is the identity there.  H * W < 2^27 (error otherwise). */
 #define MD_PHOTO_MAX_FRAMES 4
 #define MD_PHOTO_MAX_SCALES 4
 typedef struct md_photo_desc {
