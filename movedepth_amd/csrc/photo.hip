@@ -158,13 +158,13 @@ __device__ __forceinline__ void load_cams(const md_photo_desc &a, int b, float *
     }
 }
 // the same with the x and y rows of P as register pairs (md_project_pk)
-template <int F>
+template <int F, bool SG>
 __device__ __forceinline__ void load_cams_pk(const md_photo_desc &a, int b, float *camS, CamPk (&cam)[F], float (&iK)[9]) {
     load_cams_lds<F>(a, b, camS);
     // the matrices are the same in every lane: v_readfirstlane_b32 moves them to scalar registers, which the vector instructions
-    // read directly (12 F + 9 vector registers less: what lets the backward keep a frame's taps in flight, see issue_taps); up to
-    // two frames -- beyond, the scalar file is what runs out, and those kernels have vector registers to spare
-    auto uni = [](float v) { return (MD_PHOTO_CAM_SGPR && F <= 2) ? __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))) : v; };
+    // read directly (12 F + 9 vector registers less: what lets the backward keep a frame's taps in flight, see issue_taps); where
+    // the scalar file holds them without spilling (SG: forward up to two frames, backward up to three)
+    auto uni = [](float v) { return (MD_PHOTO_CAM_SGPR && SG) ? __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))) : v; };
 #pragma unroll
     for (int f = 0; f < F; ++f)
 #pragma unroll
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256, (F <= 2 ? MD_PHOTO_FWD_WAVES : 2)) void photo_
     const int x0 = (tile % tiles_x) * FT_W, y0 = (tile / tiles_x) * FT_H;
     CamPk cam[F];
     float iK[9];
-    if (!IDENT) load_cams_pk<F>(a, b, camS, cam, iK);
+    if (!IDENT) load_cams_pk<F, (F <= 2)>(a, b, camS, cam, iK);
     const size_t HW = (size_t)H * W;
     const float4 *tgt = reinterpret_cast<const float4 *>(a.target) + (size_t)b * HW;
     const float min_disp = kc.min_disp, max_disp = kc.max_disp;
@@ -486,7 +486,7 @@ __global__ __launch_bounds__(256, (F <= 2 ? MD_PHOTO_BWD_WAVES : 2)) void photo_
     }
     CamPk cam[F];
     float iK[9];
-    load_cams_pk<F>(a, b, camS, cam, iK);   // (barrier inside)
+    load_cams_pk<F, (F <= 3)>(a, b, camS, cam, iK);   // (barrier inside)
 #pragma unroll
     for (int k = 0; k < NST; ++k) {
         const int i = tid + 256 * k;
