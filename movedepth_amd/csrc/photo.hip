@@ -756,22 +756,29 @@ __global__ __launch_bounds__(256) void up_adjoint_kernel(const md_photo_desc a, 
     const int h = a.dh[s], w = a.dw[s], H = a.H, W = a.W;
     if (h == H && w == W) return;   // written by photo_bwd_kernel itself
     const int ry = (H + h - 1) / h, rx = (W + w - 1) / w;
-    int lpp = ry * rx;
-    lpp = lpp >= 64 ? 64 : (lpp >= 16 ? 16 : (lpp >= 4 ? 4 : 1));
-    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
-    const long long pixl = gid / lpp;
-    const int sub = (int)(gid % lpp);
-    const bool live = pixl < (long long)a.B * h * w;
+    // grid: (lanes of one sample, level, sample); 32-bit index arithmetic, the lanes per pixel a power of two (as 64-bit divisions
+    // the three quotients below were several hundred instructions per lane)
+    const int ll = ry * rx >= 64 ? 6 : (ry * rx >= 16 ? 4 : (ry * rx >= 4 ? 2 : 0)), lpp = 1 << ll;
+    const unsigned gid = blockIdx.x * 256u + threadIdx.x;
+    const unsigned pixl = gid >> ll;
+    const int sub = (int)(gid & (unsigned)(lpp - 1));
+    const bool live = pixl < (unsigned)(h * w);
     float acc = 0.f;
-    int b = 0, iy = 0, ix = 0;
+    const int b = blockIdx.z;
+    int iy = 0, ix = 0;
     if (live) {
-        b = (int)(pixl / ((long long)h * w));
-        const int rem = (int)(pixl - (long long)b * h * w);
-        iy = rem / w;
-        ix = rem - iy * w;
+        iy = (int)(pixl / (unsigned)w);
+        ix = (int)(pixl - (unsigned)iy * (unsigned)w);
         const bool exact = H % h == 0 && W % w == 0;
         int oy_lo, oy_hi, ox_lo, ox_hi;
-        if (exact) {
+        const bool pow2 = exact && (ry & (ry - 1)) == 0 && (rx & (rx - 1)) == 0;
+        if (pow2) {
+            // a power-of-two ratio r: the source coordinate (o + 0.5) / r - 0.5 is exact in float, and the outputs with a tap on
+            // cell i are exactly o in [r i - r/2, r i + 3r/2): 2r of them per axis, clamped taps at the borders included --
+            // 4 window elements per lane at r = 2, 4, 8 where the margin of one on either side made it 9 to 16
+            oy_lo = max(0, ry * iy - ry / 2); oy_hi = min(H - 1, ry * iy + (3 * ry) / 2 - 1);
+            ox_lo = max(0, rx * ix - rx / 2); ox_hi = min(W - 1, rx * ix + (3 * rx) / 2 - 1);
+        } else if (exact) {
             oy_lo = max(0, ry * iy - ry / 2 - 1); oy_hi = min(H - 1, ry * iy + (3 * ry) / 2 + 1);
             ox_lo = max(0, rx * ix - rx / 2 - 1); ox_hi = min(W - 1, rx * ix + (3 * rx) / 2 + 1);
         } else {
@@ -788,7 +795,29 @@ __global__ __launch_bounds__(256) void up_adjoint_kernel(const md_photo_desc a, 
         if (n == 0) acc = g[(size_t)iy * W + ix];
         const int side = lpp >= 64 ? 8 : (lpp >= 16 ? 4 : (lpp >= 4 ? 2 : 1));   // the pixel's lanes as a side x side grid
         constexpr int NC = 5;   // window columns per lane the fast path holds weights for
-        if (n > 0 && exact && side * side == lpp && fw <= side * NC) {
+        if (n > 0 && pow2 && side * side == lpp && fw <= 2 * side && oy_hi - oy_lo + 1 <= 2 * side) {
+            // r = 2, 4, 8: a lane's share of the 2r x 2r support is 2 x 2 elements -- four unconditional loads from clamped
+            // positions, in flight together (as a row loop with a skip per empty row they were two dependent round trips, and the
+            // kernel ran at the latency of its 46,000 short waves)
+            const int sub_y = sub / side, sub_x = sub % side;
+            float wx2[2], wy2[2];
+            int ox2[2], oy2[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int ox = ox_lo + sub_x + side * k, oy = oy_lo + sub_y + side * k;
+                const bool inx = ox <= ox_hi, iny = oy <= oy_hi;
+                ox2[k] = inx ? ox : ox_hi; oy2[k] = iny ? oy : oy_hi;
+                int i0, i1; float l;
+                interp_idx_s(ox2[k], w, sx, i0, i1, l);
+                wx2[k] = inx ? (i0 == ix ? 1.f - l : 0.f) + (i1 == ix ? l : 0.f) : 0.f;
+                interp_idx_s(oy2[k], h, sy, i0, i1, l);
+                wy2[k] = iny ? (i0 == iy ? 1.f - l : 0.f) + (i1 == iy ? l : 0.f) : 0.f;
+            }
+            const float g00 = g[(size_t)oy2[0] * W + ox2[0]], g01 = g[(size_t)oy2[0] * W + ox2[1]];
+            const float g10 = g[(size_t)oy2[1] * W + ox2[0]], g11 = g[(size_t)oy2[1] * W + ox2[1]];
+            acc += g00 * wy2[0] * wx2[0]; acc += g01 * wy2[0] * wx2[1];
+            acc += g10 * wy2[1] * wx2[0]; acc += g11 * wy2[1] * wx2[1];
+        } else if (n > 0 && exact && side * side == lpp && fw <= side * NC) {
             // lane (sub / side, sub % side) takes window rows sub_y + side * j and columns sub_x + side * i: no division by the
             // window width per element (the index arithmetic of the flat loop below was 70 instructions per element: 28 us of the
             // kernel's 42), and the weights are separable: a column's is formed once per lane, a row's once per row -- formed per
@@ -962,11 +991,12 @@ extern "C" int md_photo_bwd(const md_photo_desc *d, void *ws, md_stream_t stream
             if (d->dh[s] == d->H && d->dw[s] == d->W) continue;   // photo_bwd_kernel wrote d_dz[s] itself
             int lpp = md_cdiv(d->H, d->dh[s]) * md_cdiv(d->W, d->dw[s]);
             lpp = lpp >= 64 ? 64 : (lpp >= 16 ? 16 : (lpp >= 4 ? 4 : 1));
-            const long long n = (long long)d->B * d->dh[s] * d->dw[s] * lpp;
+            const long long n = (long long)d->dh[s] * d->dw[s] * lpp;   // lanes of one sample
             mx = n > mx ? n : mx;
         }
         if (mx > 0) {
-            MD_LAUNCH_TIMED("md_photo_bwd", up_adjoint_kernel, dim3((unsigned)md_cdiv(mx, 256), d->S), dim3(256), 0, st, *d, (const float *)gup);
+            MD_REQUIRE(mx < (1ll << 31), "md_photo_bwd: a disparity level of %lld lanes per sample", mx);
+            MD_LAUNCH_TIMED("md_photo_bwd", up_adjoint_kernel, dim3((unsigned)md_cdiv(mx, 256), d->S, d->B), dim3(256), 0, st, *d, (const float *)gup);
             MD_CHECK_LAUNCH("md_photo_bwd(up-sampling adjoint)");
         }
     }
