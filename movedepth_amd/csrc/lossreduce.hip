@@ -105,6 +105,12 @@ __global__ __launch_bounds__(256) void smooth_mean_kernel(const SmoothArgs a, fl
     const int b = blockIdx.y, lv = blockIdx.z, B = a.B, hw = a.h[lv] * a.w[lv];
     float *ws = wsall + lv * sm_ws_floats(B);
     const float *disp = a.disp[lv];
+    // A block without a pixel (the coarse levels fill 8 to 120 of the SM_BLK blocks a sample gets) leaves its zero and goes: run in
+    // full -- the mean's 256 loads, three block sums -- the empty blocks were 60 % of the launch's workgroups and most of its time.
+    if (blockIdx.x * 256 >= hw) {
+        if (threadIdx.x == 0) ws[B + (size_t)B * SM_BLK * 3 + (size_t)b * SM_BLK + blockIdx.x] = 0.f;
+        return;
+    }
     float s = 0.f;
     for (int p = blockIdx.x * 256 + threadIdx.x; p < hw; p += SM_BLK * 256) s += disp[(size_t)b * hw + p];
     s = block_sum(s, red);
@@ -126,6 +132,10 @@ __global__ __launch_bounds__(256) void smooth_fwd_kernel(const SmoothArgs a, flo
     __shared__ float red[4];
     const int b = blockIdx.y, lv = blockIdx.z, B = a.B, Ci = a.Ci, h = a.h[lv], w = a.w[lv], hw = h * w;
     float *ws = wsall + lv * sm_ws_floats(B);
+    if (blockIdx.x * 256 >= hw) {   // no pixel: see smooth_mean_kernel
+        if (threadIdx.x == 0) { float *part = ws + B + ((size_t)b * SM_BLK + blockIdx.x) * 2; part[0] = 0.f; part[1] = 0.f; }
+        return;
+    }
     const float dn = a.normalize ? sample_mean(ws, B, b, hw, red) + 1e-7f : 1.f;
     const float *d = a.disp[lv] + (size_t)b * hw, *im = a.img[lv] + (size_t)b * Ci * hw;
     float sx = 0.f, sy = 0.f;
@@ -159,6 +169,10 @@ __global__ __launch_bounds__(256) void smooth_bwd_kernel(const SmoothArgs a, flo
     __shared__ float red[4];
     const int b = blockIdx.y, lv = blockIdx.z, B = a.B, Ci = a.Ci, h = a.h[lv], w = a.w[lv], hw = h * w;
     float *ws = wsall + lv * sm_ws_floats(B);
+    if (blockIdx.x * 256 >= hw) {   // no pixel: see smooth_mean_kernel
+        if (threadIdx.x == 0) ws[B + (size_t)B * SM_BLK * 2 + (size_t)b * SM_BLK + blockIdx.x] = 0.f;
+        return;
+    }
     const float dn = a.normalize ? sample_mean(ws, B, b, hw, red) + 1e-7f : 1.f;
     const float gl = a.gloss[lv] ? a.gloss[lv][0] : 0.f;
     const float cx = gl / ((float)B * h * (w - 1)), cy = gl / ((float)B * (h - 1) * w);
@@ -186,6 +200,7 @@ __global__ __launch_bounds__(256) void smooth_bwd_finish_kernel(const SmoothArgs
     const int b = blockIdx.y, lv = blockIdx.z, B = a.B, hw = a.h[lv] * a.w[lv];
     const float *ws = wsall + lv * sm_ws_floats(B);
     float *d_disp = a.d_disp[lv];
+    if (blockIdx.x * 256 >= hw) return;   // no pixel
     const float dn = sample_mean(ws, B, b, hw, red) + 1e-7f;
     const float dot = block_sum(threadIdx.x < SM_BLK ? ws[B + (size_t)B * SM_BLK * 2 + (size_t)b * SM_BLK + threadIdx.x] : 0.f, red);
     const float corr = dot / (dn * dn) / (float)hw;
