@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Micro-benchmark of the fused photometric kernels at BASELINE config 2 (B=6, 192x640, 2 source frames): the mono group
 (4 scales, disparity pyramid, auto-mask), the MVS group and the fused-depth group.  Wall time per call from torch events
-(includes the Python wrapper); run under `rocprofv3 --kernel-trace --stats` for the kernels' own durations.  GPU only."""
+(includes the Python wrapper); run under `rocprofv3 --kernel-trace --stats` for the kernels' own durations.  GPU only.
+WANT_PIX=0: the mono group without its sample-grid outputs (what the trainer asks for with --lazy_sample_grids 1)."""
 import argparse
 import os
 import sys
