@@ -435,7 +435,9 @@ def main():
     # memory-bound -- the vector ALU is the busiest unit (~52 % of the cycles beside the per-pixel gathers; 13-27 % of HBM): the counters
     # are in profiles/r06_photo_pmc.txt -- the figure is here because the roofline of every hot-path kernel is asked for.
     if not a.trainer_args and opt.height == 192 and opt.width == 640 and opt.batch_size == 6:
-        for k_, nbytes in (("md_photo_fwd", 222e6 + 2 * 74e6 + 38e6), ("md_photo_bwd", 148e6 + 2 * 74e6 * 148.0 / 222.0)):
+        # (with --lazy_sample_grids the mono forward does not write its 8 sample grids: 8 x B*H*W*8 B = 47 MB less)
+        grids = 0.0 if getattr(opt, "lazy_sample_grids", 0) else 8 * opt.batch_size * opt.height * opt.width * 8.0
+        for k_, nbytes in (("md_photo_fwd", 222e6 - 47.2e6 + grids + 2 * 74e6 + 38e6), ("md_photo_bwd", 148e6 + 2 * 74e6 * 148.0 / 222.0)):
             if k_ in photo_in_step:
                 e_ = photo_in_step[k_]
                 e_["algorithmic_bytes_per_step"] = nbytes
